@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/s of detect() = forward + YOLO decode + MERGE-NMS on synthetic
+640x640 batches, YOLOv3-SPP, bs=32 per MI355X (BASELINE.json).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the whole hot path over one batch of 32 images per GPU (inputs already
+resident in HBM).  For N>1 every rank runs its own 32 images (weak scaling) and the per-rank
+detections are all-gathered (RCCL) inside the timed step.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from pytorch_yolo_amd import YOLOv3SPP, YOLOv3Tiny, YOLOv3TinyMobile          # noqa: E402
+from pytorch_yolo_amd.distributed import gather_detections                  # noqa: E402
+from pytorch_yolo_amd.utils.synthetic import synth_images, synth_state_dict  # noqa: E402
+from pytorch_yolo_amd.utils.utils import nms_capacity, nms_raw               # noqa: E402
+from pytorch_yolo_amd import kernels as K                                    # noqa: E402
+
+SPP_ANCHORS = (((10., 13.), (16., 30.), (33., 23.)), ((30., 61.), (62., 45.), (59., 119.)),
+               ((116., 90.), (156., 198.), (373., 326.)))
+# algorithmic conv work per image: 2 x MACs of the conv layers only
+GFLOP_PER_IMG = {"spp": 156.73, "tiny": 5.565, "mobile": 2.572}
+PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+WORKLOADS = {
+    "spp": dict(cls=YOLOv3SPP, kw=dict(anchors=SPP_ANCHORS), hw=640, bs=32,
+                name="YOLOv3-SPP Darknet74 640x640 bs=32/GPU detect() = forward+decode+MERGE-NMS"),
+    "tiny": dict(cls=YOLOv3Tiny, kw=dict(), hw=416, bs=32,
+                 name="YOLOv3-tiny Darknet-15 416x416 bs=32/GPU detect()"),
+    "mobile": dict(cls=YOLOv3TinyMobile, kw=dict(), hw=416, bs=64,
+                   name="YOLOv3-tiny MobileNetV2 416x416 bs=64/GPU detect()"),
+}
+CONF_THRES, NMS_THRES = 0.1, 0.5
+
+
+def conv_flops(plan) -> float:
+    """Exact algorithmic FLOPs of the recorded conv launches (2*M*Cout*K, logical sizes)."""
+    from pytorch_yolo_amd._lib import OP_CONV, OP_DWCONV
+    total = 0.0
+    for i in range(plan.n_ops):
+        op = plan.op_array[i]
+        d = op.conv
+        if op.kind == OP_CONV:
+            cin = 3 if (d.cin == 8 and i == 0) else d.cin
+            total += 2.0 * d.n * d.ho * d.wo * d.cout * d.ksize * d.ksize * cin
+        elif op.kind == OP_DWCONV:
+            total += 2.0 * d.n * d.ho * d.wo * d.cin * 9
+    return total
+
+
+def cpu_baseline(workload: str, seconds_budget: float = 25.0):
+    """The oracle (CPU restatement of the reference path) timed on this box's host cores."""
+    import numpy as np
+    from oracle import models as om
+    from oracle import nms as onms
+    if workload != "spp":
+        fwd, anchors, hw = om.tiny_forward, om.TINY_ANCHORS, 416
+        tmpl = YOLOv3Tiny().state_dict()
+    else:
+        fwd, anchors, hw = om.spp_forward, om.SPP_ANCHORS, 640
+        tmpl = YOLOv3SPP(anchors=SPP_ANCHORS).state_dict()
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    torch.set_num_threads(cores)
+    sd = synth_state_dict(tmpl, 1234, n_class=80)
+    bs = 4
+    x = synth_images(bs, hw, hw, 0)
+    with torch.no_grad():
+        fwd(sd, x[:1], anchors, 80)                      # warm-up (thread pool, MKLDNN primitives)
+        t0 = time.time()
+        iters = 0
+        while True:
+            io, _ = fwd(sd, x, anchors, 80)
+            onms.non_max_suppression(io.numpy(), CONF_THRES, NMS_THRES)
+            iters += 1
+            if time.time() - t0 > seconds_budget or iters >= 3:
+                break
+    dt = time.time() - t0
+    return dict(value=round(bs * iters / dt, 3), unit="images/s", cores=cores, kind="port",
+                sample=f"oracle fp32 torch forward + numpy MERGE-NMS, {iters} x bs={bs} {hw}x{hw}, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="spp", choices=list(WORKLOADS))
+    ap.add_argument("--bs", type=int, default=0, help="images per GPU (default: the BASELINE config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the forward as a captured HIP graph")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    wl = WORKLOADS[args.workload]
+    bs = args.bs or wl["bs"]
+    model = wl["cls"](**wl["kw"]).eval()
+    model.load_state_dict(synth_state_dict(model.state_dict(), 1234, n_class=80))
+    model = model.to(dev)
+    x = synth_images(bs, wl["hw"], wl["hw"], seed=rank).to(dev)      # per-rank images, resident in HBM
+
+    plan = model.plan_for(x)
+    rows, nc = plan.rows_total, model.n_class
+    cap = nms_capacity(rows, nc)
+    nms_out = (torch.empty((bs, cap, 7), dtype=torch.float32, device=dev),
+               torch.empty((bs, cap), dtype=torch.int32, device=dev),
+               torch.empty((bs,), dtype=torch.int32, device=dev))
+    io, ps = plan.new_outputs()
+    flops_step = conv_flops(plan)
+
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * (args.steps + args.warmup))]
+    conv_ms = []
+
+    def step(i):
+        """pack -> 76 conv launches (+pools) -> 3 decodes -> NMS (-> all-gather). HIP events bracket the
+        conv launch list on the stream it is launched on (torch's current stream)."""
+        K.pack_input(x, plan.input_buffer)
+        ev[2 * i].record()
+        K.run_ops(plan.op_array, plan.n_ops)
+        ev[2 * i + 1].record()
+        for hd, p in zip(plan.heads, ps):
+            K.decode(hd["sym"].buf.tensor, hd["anchors"], nc, hd["stride"], io, hd["row"], p)
+        nms_raw(io, CONF_THRES, NMS_THRES, out=nms_out)
+        if world > 1:
+            return gather_detections(nms_out[0], nms_out[2])
+        return nms_out[0], nms_out[2]
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for i in range(args.warmup):
+            step(i)
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(args.warmup, args.warmup + args.steps):
+            dets, counts = step(i)
+        sync_all()
+        dt = time.perf_counter() - t0
+    for i in range(args.warmup, args.warmup + args.steps):
+        conv_ms.append(ev[2 * i].elapsed_time(ev[2 * i + 1]))
+    n_dets = counts.cpu().tolist()
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+
+    if rank == 0:
+        total_imgs = bs * world * args.steps
+        conv_ms_avg = sum(conv_ms) / len(conv_ms)
+        achieved = flops_step / (conv_ms_avg * 1e-3) / 1e12
+        out = {
+            "metric": "images/sec YOLOv3-SPP 640x640 bs=32 detect()" if args.workload == "spp" else f"images/sec {wl['name']}",
+            "value": round(total_imgs / dt_max, 2),
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt_max / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": wl["name"], "images_per_gpu": bs, "global_batch": bs * world,
+                       "n_class": nc, "conf_thres": CONF_THRES, "nms_thres": NMS_THRES,
+                       "sharding": f"batch x{world}" + (" + RCCL all-gather of detections" if world > 1 else ""),
+                       "mean_detections_per_image": round(sum(n_dets) / max(1, len(n_dets)), 1)},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "kernel": "conv_igemm_bf16_kernel (all conv launches of one forward)",
+                         "flops_per_step": flops_step, "ms_per_step_conv": round(conv_ms_avg, 4)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

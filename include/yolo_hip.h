@@ -1,0 +1,134 @@
+/*
+ * yolo_hip.h — C ABI of libyolo_hip.so: the MI355X (gfx950) YOLOv3 inference hot path.
+ *
+ * The reference (Dipet/pytorch_yolo) has no FFI: its seam is the nn.Module API.  Each entry
+ * point below replaces the ATen dispatches of one reference function (file:line relative to
+ * /root/reference/pytorch_yolo) and is what a ctypes stub on the reference side would bind
+ * (INTEGRATION.md shows that stub).
+ *
+ * Conventions
+ *  - plain pointers + sizes only; every device buffer is owned by the caller (torch tensors);
+ *    the library never allocates, frees or retains device memory.
+ *  - asynchronous launch on the caller's hipStream_t; no internal synchronisation; graph-capturable.
+ *  - return 0 on success; >0 = hipError_t from the launch; <0 = YOLO_E_* argument error.
+ *    yolo_last_error() returns a thread-local message for the last non-zero return.
+ *  - activations are NHWC; "view" = (base pointer, c_offset, c_total): channel c of pixel p lives at
+ *    base[p * c_total + c_offset + c].  bf16 activation channel counts/offsets are multiples of 8.
+ */
+#ifndef YOLO_HIP_H
+#define YOLO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* yolo_stream_t; /* hipStream_t */
+
+#if defined(__GNUC__)
+#define YOLO_API __attribute__((visibility("default")))
+#else
+#define YOLO_API
+#endif
+
+enum { YOLO_E_ARG = -1, YOLO_E_UNSUPPORTED = -2, YOLO_E_WORKSPACE = -3 };
+enum { YOLO_ACT_NONE = 0, YOLO_ACT_LEAKY01 = 1, YOLO_ACT_RELU6 = 2 };
+enum { YOLO_DT_BF16 = 0, YOLO_DT_F32 = 1 };
+
+YOLO_API const char* yolo_last_error(void);
+YOLO_API int yolo_abi_version(void);
+
+/* ---- input packing: the `imgs.to(device)` + first-layer layout step (utils/utils.py:374) -----
+ * x: f32 NCHW [n,c,h,w]  ->  y: bf16 NHWC [n,h,w,c_pad] (channels c..c_pad-1 zero). */
+YOLO_API int yolo_pack_input_nchw_f32(const float* x, void* y, int n, int c, int h, int w, int c_pad,
+                             yolo_stream_t s);
+
+/* ---- ConvBlock.forward (models/yolo_base.py:19-44) with the BN already folded
+ *      (utils/torch_utils.py:33-60), plain nn.Conv2d heads (models/yolov3_tiny.py:38,42),
+ *      and the element-wise neighbours fused into the epilogue:
+ *      Add (models/yolov3_spp.py:12-14), Upsample x2 (models/yolo_layer.py:6-13),
+ *      Concat placement (models/yolo_layer.py:16-22).
+ *
+ *  y = act(conv(x, W) + bias);  if y_preadd: y_preadd = y;  if residual: y += residual;  store.
+ *  Implicit GEMM on MFMA 32x32x16 bf16, fp32 accumulate.  groups == 1.
+ */
+typedef struct YoloConvDesc {
+  int32_t n, h, w;                 /* input batch / spatial size                           */
+  int32_t cin;                     /* logical input channels, multiple of 8                */
+  int32_t in_c_total, in_c_offset; /* input view                                           */
+  int32_t ho, wo;                  /* conv output spatial size (before optional upsample)  */
+  int32_t cout;                    /* logical output channels                              */
+  int32_t out_c_total, out_c_offset;
+  int32_t ksize, stride, pad;      /* square kernel 1 or 3; zero padding                   */
+  int32_t act;                     /* YOLO_ACT_*                                           */
+  int32_t upsample2x;              /* 1: each output pixel is written to a 2x2 block of a
+                                      [n,2ho,2wo,out_c_total] tensor                       */
+  int32_t out_dtype;               /* YOLO_DT_BF16 | YOLO_DT_F32 (detection heads)         */
+  int32_t kpad;                    /* packed K = roundup(ksize*ksize*cin, 32)              */
+  int32_t cout_pad;                /* packed rows = roundup(cout, 128) (zero rows)         */
+  int32_t res_c_total, res_c_offset; /* residual view (bf16), same spatial size as output  */
+  int32_t aux_c_total, aux_c_offset; /* pre-add copy view (bf16)                           */
+} YoloConvDesc;
+
+/* w_packed: bf16 [cout_pad][kpad], k = (kh*ksize + kw)*cin + c  (yolo_pack_conv_weight_f32).
+ * bias: f32 [cout_pad].  residual / y_preadd may be NULL. */
+YOLO_API int yolo_conv2d_fwd(const void* x, const void* w_packed, const float* bias, const void* residual,
+                    void* y, void* y_preadd, const YoloConvDesc* d, yolo_stream_t s);
+
+/* host-side helper (CPU): OIHW f32 [cout,cin_w,k,k] -> packed bf16 (round-to-nearest-even);
+ * cin_w <= cin (extra input channels, e.g. the RGB->8 pad, get zero weights). */
+YOLO_API int yolo_pack_conv_weight_f32(const float* w_oihw, int cout, int cin_w, int ksize, int cin,
+                              int cout_pad, int kpad, uint16_t* out);
+
+/* ---- depthwise 3x3 conv + bias + act (MobileNetV2 inverted residual; torchvision, see
+ *      models/yolov3_tiny_mobilenet.py:11-34).  w: f32 [9][c] tap-major, bias f32 [c]. */
+YOLO_API int yolo_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int n, int h, int w_,
+                       int c, int in_c_total, int in_c_offset, int ho, int wo, int out_c_total,
+                       int out_c_offset, int stride, int act, yolo_stream_t s);
+
+/* ---- MaxPool (models/yolo_base.py:60-66): -inf padding; the (2,1) special is pad 1, dilation 2. */
+YOLO_API int yolo_maxpool_fwd(const void* x, void* y, int n, int h, int w, int c, int in_c_total, int in_c_offset,
+                     int ho, int wo, int out_c_total, int out_c_offset, int ksize, int stride, int pad,
+                     int dilation, yolo_stream_t s);
+
+/* ---- SPP pyramid (models/yolov3_spp.py:75-77,129): buf is the [n,h,w,4c] concat buffer whose
+ *      slice [3c,4c) already holds x; writes pool5 -> [0,c), pool9 -> [c,2c), pool13 -> [2c,3c). */
+YOLO_API int yolo_spp_fwd(void* buf, int n, int h, int w, int c, yolo_stream_t s);
+
+/* ---- YOLOLayer.forward eval branch (models/yolo_layer.py:57-69,90-111).
+ *  head: f32 NHWC [bs,ny,nx,head_c_total], channel a*(5+nc)+k.
+ *  io:   f32 [bs, io_rows_total, 5+nc]; this head fills rows [io_row_offset, +na*ny*nx).
+ *  p:    f32 [bs,na,ny,nx,5+nc] or NULL.
+ *  anchors_px: host array of na*2 floats (pixels).  stride_px = img_size / max(nx,ny). */
+YOLO_API int yolo_decode_fwd(const float* head, int head_c_total, const float* anchors_px, int na, int nc, int bs,
+                    int ny, int nx, float stride_px, float* io, int io_rows_total, int io_row_offset,
+                    float* p, yolo_stream_t s);
+
+/* ---- non_max_suppression, 'MERGE' style (utils/utils.py:200-293; xywh2xyxy :46-60, bbox_iou :63-96).
+ *  pred: f32 [bs,rows,5+nc].  If mutate_conf != 0 column 4 is overwritten with obj*max_cls like the
+ *  reference (:213); otherwise pred is read-only.
+ *  out_dets [bs,cap,7] (x1,y1,x2,y2,conf,cls_conf,cls), out_idx [bs,cap] = pivot row of each output,
+ *  out_count [bs].  Rows are ordered by conf descending (ties: class, then pivot order).
+ *  cap >= min(rows, nc*max_per_class) guarantees nothing is dropped; if an image would exceed cap,
+ *  out_count holds the true count and only the first cap rows are written. */
+YOLO_API size_t yolo_nms_workspace_bytes(int bs, int rows, int nc);
+YOLO_API int yolo_nms_merge(float* pred, int bs, int rows, int nc, float conf_thres, float nms_thres, float min_wh,
+                   int max_per_class, int mutate_conf, float* out_dets, int32_t* out_idx,
+                   int32_t* out_count, int cap, void* workspace, size_t workspace_bytes, yolo_stream_t s);
+
+/* ---- batched launcher: run a recorded list of ops with one FFI crossing (host overhead only). */
+enum { YOLO_OP_CONV = 1, YOLO_OP_MAXPOOL = 2, YOLO_OP_SPP = 3, YOLO_OP_DWCONV = 4 };
+typedef struct YoloOp {
+  int32_t kind, _pad;
+  const void* x; const void* w; const float* bias; const void* residual; void* y; void* y_aux;
+  YoloConvDesc conv;             /* kind CONV; DWCONV/MAXPOOL/SPP reuse the geometry fields
+                                    (ksize/stride/pad, act, views); MAXPOOL dilation = upsample2x field */
+} YoloOp;
+YOLO_API int yolo_run_ops(const YoloOp* ops, int n_ops, yolo_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLO_HIP_H */

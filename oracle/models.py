@@ -1,0 +1,116 @@
+"""Oracle model graphs (functional, fp32, CPU torch).  TEST INFRASTRUCTURE.
+
+Restates the wiring of the three model families in BASELINE.json's configs.
+All functions take a reference-keyed ``state_dict`` and return what the
+reference's ``forward`` returns in eval mode: ``(io, (p_0, p_1, ...))``.
+"""
+from __future__ import annotations
+
+import torch
+
+from .blocks import (conv_bn_leaky, max_pool, plain_conv1x1, upsample2,
+                     yolo_decode)
+
+SPP_STAGE_REPEATS = (1, 2, 8, 8, 4)   # DownSample(repeat=0,1,7,7,3)+1, yolov3_spp.py:63-67,22
+
+# Anchor sets used throughout tests / bench.
+SPP_ANCHORS = (((10., 13.), (16., 30.), (33., 23.)),
+               ((30., 61.), (62., 45.), (59., 119.)),
+               ((116., 90.), (156., 198.), (373., 326.)))       # order of yolov3_spp.py:196-198
+TINY_ANCHORS = (((10., 14.), (23., 27.), (37., 58.)),
+                ((81., 82.), (135., 169.), (344., 319.)))       # yolo_base.py:88-89
+
+
+def darknet_stage(sd, prefix, x, repeats):
+    """DownSample.forward — yolov3_spp.py:38-46.
+
+    Returns (x_after_last_add, sub) where ``sub`` is the LAST residual branch
+    output *before* its add (the reference's route tensors are pre-add).
+    """
+    x = conv_bn_leaky(sd, f"{prefix}.conv0", x, stride=2)
+    sub = x
+    for i in range(repeats):
+        sub = conv_bn_leaky(sd, f"{prefix}.seq{i}.0", x)            # 1x1 C -> C/2
+        sub = conv_bn_leaky(sd, f"{prefix}.seq{i}.1", sub)          # 3x3 C/2 -> C
+        x = x + sub                                                 # Add, :12-14
+    return x, sub
+
+
+def spp_encoder(sd, x):
+    """YOLOv3SPP._forward_encoder — yolov3_spp.py:119-139."""
+    x = conv_bn_leaky(sd, "conv1", x)
+    subs = []
+    for i, rep in enumerate(SPP_STAGE_REPEATS, start=1):
+        x, sub = darknet_stage(sd, f"down{i}", x, rep)
+        subs.append(sub)
+    for n in ("conv1", "conv2", "conv3"):
+        x = conv_bn_leaky(sd, f"sequence_spp.{n}", x)
+    x = torch.cat([max_pool(x, 5, 1), max_pool(x, 9, 1), max_pool(x, 13, 1), x], 1)  # :129
+    for n in ("conv1", "conv2", "conv3"):
+        x = conv_bn_leaky(sd, f"branch1_1.{n}", x)
+    b1 = conv_bn_leaky(sd, "branch1_2.conv1", x)
+    b1 = conv_bn_leaky(sd, "branch1_2.conv2", b1)                   # head is a ConvBlock (:86)
+
+    y = upsample2(conv_bn_leaky(sd, "branch2_1.0", x))
+    y = torch.cat([y, subs[3]], 1)                                  # :133
+    for n in ("conv1", "conv2", "conv3", "conv4", "conv5"):
+        y = conv_bn_leaky(sd, f"branch2_2.{n}", y)
+    b2 = conv_bn_leaky(sd, "branch2_3.conv6", y)
+    b2 = conv_bn_leaky(sd, "branch2_3.conv7", b2)
+
+    z = upsample2(conv_bn_leaky(sd, "branch3_1.0", y))
+    z = torch.cat([z, subs[2]], 1)                                  # :137
+    for n in ("conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7"):
+        z = conv_bn_leaky(sd, f"branch3_2.{n}", z)
+    return b1, b2, z
+
+
+def spp_forward(sd, x, anchors=SPP_ANCHORS, n_class=80):
+    """YOLOv3SPP.forward (eval) — yolov3_spp.py:141-164."""
+    img_size = max(x.shape[-2:])
+    heads = spp_encoder(sd, x)
+    outs = [yolo_decode(h, a, n_class, img_size) for h, a in zip(heads, anchors)]
+    io, p = zip(*outs)
+    return torch.cat(io, 1), tuple(p)
+
+
+def tiny_encoder(sd, x):
+    """YOLOv3Tiny._forward_encoder — yolov3_tiny.py:67-77 (+ ctor :18-43)."""
+    for i in (1, 2, 3, 4):                                          # ConvPoolBlock 2/2
+        x = max_pool(conv_bn_leaky(sd, f"sequence_1.conv{i}", x), 2, 2)
+    route1 = conv_bn_leaky(sd, "sequence_1.conv5", x)
+    y = max_pool(route1, 2, 2)                                      # nn.MaxPool2d(2,2), :26
+    y = max_pool(conv_bn_leaky(sd, "sequence_2.conv6", y), 2, 1)    # dilated special
+    y = conv_bn_leaky(sd, "sequence_2.conv7", y)
+    route2 = conv_bn_leaky(sd, "sequence_2.conv8", y)
+    return _tiny_heads(sd, route1, route2)
+
+
+def _tiny_heads(sd, route1, route2):
+    """Shared tiny-style head — yolov3_tiny.py:30-43,72-77 and
+    yolov3_tiny_mobilenet.py:58-69,81-86 (same wiring, different widths)."""
+    up = upsample2(conv_bn_leaky(sd, "sequence_branch1_1.branch1_conv1", route2))
+    b1 = torch.cat([route1, up], 1)                                 # order [route1, up], :73
+    b1 = conv_bn_leaky(sd, "sequence_branch1_2.branch1_conv2", b1)
+    b1 = plain_conv1x1(sd, "sequence_branch1_2.branch1_conv3", b1)
+    b2 = conv_bn_leaky(sd, "sequence_branch2.branch2_conv1", route2)
+    b2 = plain_conv1x1(sd, "sequence_branch2.branch2_conv2", b2)
+    return b1, b2
+
+
+def tiny_forward(sd, x, anchors=TINY_ANCHORS, n_class=80):
+    """YOLOv3Tiny.forward (eval) — yolov3_tiny.py:79-100."""
+    img_size = max(x.shape[-2:])
+    heads = tiny_encoder(sd, x)
+    outs = [yolo_decode(h, a, n_class, img_size) for h, a in zip(heads, anchors)]
+    io, p = zip(*outs)
+    return torch.cat(io, 1), tuple(p)
+
+
+def tiny_mobile_head_forward(sd, route1, route2, img_size, anchors=TINY_ANCHORS, n_class=80):
+    """The reference-owned part of YOLOv3TinyMobile — yolov3_tiny_mobilenet.py:78-109
+    with the encoder outputs (96ch @/16, 1280ch @/32) supplied by the caller."""
+    heads = _tiny_heads(sd, route1, route2)
+    outs = [yolo_decode(h, a, n_class, img_size) for h, a in zip(heads, anchors)]
+    io, p = zip(*outs)
+    return torch.cat(io, 1), tuple(p)

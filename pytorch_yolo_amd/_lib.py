@@ -1,0 +1,78 @@
+"""ctypes binding of libyolo_hip.so (include/yolo_hip.h).
+
+There is NO fallback: if the shared library is missing or a symbol does not
+resolve, importing the kernels raises.  The product path never runs on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libyolo_hip.so")
+
+ACT_NONE, ACT_LEAKY01, ACT_RELU6 = 0, 1, 2
+DT_BF16, DT_F32 = 0, 1
+OP_CONV, OP_MAXPOOL, OP_SPP, OP_DWCONV = 1, 2, 3, 4
+
+
+class YoloConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "n", "h", "w", "cin", "in_c_total", "in_c_offset", "ho", "wo", "cout",
+        "out_c_total", "out_c_offset", "ksize", "stride", "pad", "act", "upsample2x",
+        "out_dtype", "kpad", "cout_pad", "res_c_total", "res_c_offset",
+        "aux_c_total", "aux_c_offset")]
+
+
+class YoloOp(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("_pad", C.c_int32),
+                ("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p),
+                ("residual", C.c_void_p), ("y", C.c_void_p), ("y_aux", C.c_void_p),
+                ("conv", YoloConvDesc)]
+
+
+# symbol -> (restype, argtypes); kept in one table so tests can check it against the header
+SIGNATURES = {
+    "yolo_last_error": (C.c_char_p, []),
+    "yolo_abi_version": (C.c_int, []),
+    "yolo_pack_input_nchw_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
+    "yolo_conv2d_fwd": (C.c_int, [C.c_void_p] * 6 + [C.POINTER(YoloConvDesc), C.c_void_p]),
+    "yolo_pack_conv_weight_f32": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
+    "yolo_dwconv3x3_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 12 + [C.c_void_p]),
+    "yolo_maxpool_fwd": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 14 + [C.c_void_p]),
+    "yolo_spp_fwd": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
+    "yolo_decode_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 5 + [C.c_float, C.c_void_p,
+                                  C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "yolo_nms_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
+    "yolo_nms_merge": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [C.c_float] * 3 + [C.c_int] * 2 +
+                       [C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "yolo_run_ops": (C.c_int, [C.POINTER(YoloOp), C.c_int, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and type the library.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m pytorch_yolo_amd.build` "
+            "(hipcc --offload-arch=gfx950). pytorch_yolo_amd has no CPU / eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.yolo_abi_version() != 1:
+        raise RuntimeError("libyolo_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().yolo_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libyolo_hip {what} failed (code {rc}): {msg}")

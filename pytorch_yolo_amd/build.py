@@ -1,0 +1,57 @@
+"""In-tree build of libyolo_hip.so for gfx950 (hipcc cross-compiles without a GPU).
+
+    python -m pytorch_yolo_amd.build [--force]
+
+The .so stays next to the sources (git-ignored, but it travels with gpurun snapshots).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(CSRC, "libyolo_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+# per-file extra flags: nms.hip must not contract a*b+c into fma (bit-exact IoU, see its header)
+SOURCES = {
+    "runtime.hip": [],
+    "conv_igemm.hip": [],
+    "pointwise.hip": [],
+    "nms.hip": ["-ffp-contract=off"],
+}
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+          "-Wall", "-Wno-unused-function"]
+
+
+def _stale(out: str, deps) -> bool:
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    headers = [os.path.join(CSRC, "common.h"),
+               os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "yolo_hip.h")]
+    objs = []
+    for src, extra in SOURCES.items():
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            cmd = [HIPCC, *COMMON, *extra, "-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+    if force or _stale(LIB_PATH, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

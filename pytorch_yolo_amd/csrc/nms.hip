@@ -1,0 +1,365 @@
+// Batched confidence-weighted "MERGE" NMS for gfx950 (wave64 primitives, LDS sort).
+//
+// Replaces the Python loops of non_max_suppression (reference utils/utils.py:200-293, style 'MERGE'
+// :240,:266-275) with xywh2xyxy (:46-60) and bbox_iou (:63-96).
+//
+// Bit-exactness contract: every floating-point step that decides WHICH rows survive (conf product,
+// thresholds, box corners, IoU) is a single IEEE fp32 operation in the reference's order — this file is
+// compiled with -ffp-contract=off and uses correctly rounded division — so kept-index sets equal the
+// CPU oracle's exactly.  The merged box is accumulated sequentially in candidate order (oracle/nms.py).
+//
+// Two kernels:
+//   nms_filter : all rows, HBM-bound.  Row tiles are staged in LDS with coalesced loads, one lane then
+//                owns one row: class max/argmax, conf = obj*cls, thresholds, finite check; survivors are
+//                appended (wave-aggregated atomic) as 64-bit sort keys  class | ~conf | row.
+//   nms_merge  : one 1024-thread workgroup per image: bitonic sort of the keys (LDS up to 8192 keys,
+//                global workspace beyond), class segments, one wave per class runs the sequential
+//                MERGE over its first max_per_class rows with ballot masks, final sort by conf.
+#include "common.h"
+
+namespace {
+
+typedef unsigned long long u64;
+
+constexpr int kLdsKeys = 8192;     // keys sorted in LDS; more survivors -> sort in the global workspace
+constexpr int kMaxClasses = 1024;
+constexpr int kMaxPerClassCap = 128;  // 2 candidates per lane
+constexpr int kMergeThreads = 1024;
+constexpr int kMergeWaves = kMergeThreads / 64;
+constexpr int kFilterRows = 64;
+
+// monotone float -> uint map (ascending), valid for every non-NaN float
+__device__ __forceinline__ uint32_t f32_sortable(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float f32_unsortable(uint32_t s) {
+  return __uint_as_float((s & 0x80000000u) ? (s & 0x7fffffffu) : ~s);
+}
+// key = class:12 | ~sortable(conf):32 | row:20   -> ascending key == (class asc, conf desc, row asc)
+__device__ __forceinline__ u64 make_key(int cls, float conf, int row) {
+  return ((u64)cls << 52) | ((u64)(~f32_sortable(conf)) << 20) | (u64)row;
+}
+__device__ __forceinline__ int key_class(u64 k) { return (int)(k >> 52); }
+__device__ __forceinline__ float key_conf(u64 k) { return f32_unsortable(~(uint32_t)(k >> 20)); }
+__device__ __forceinline__ int key_row(u64 k) { return (int)(k & 0xfffffu); }
+
+__device__ __forceinline__ bool finite_f(float v) { return (__float_as_uint(v) & 0x7f800000u) != 0x7f800000u; }
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nms_filter_kernel(float* __restrict__ pred, int rows, int no, float conf_thres,
+                                                         float min_wh, int mutate, u64* __restrict__ keys,
+                                                         long key_pitch, int* __restrict__ counts) {
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  float* tile = reinterpret_cast<float*>(lds_raw);
+  const int b = blockIdx.y;
+  const int r0 = blockIdx.x * kFilterRows;
+  const int nrows = min(kFilterRows, rows - r0);
+  float* src = pred + ((long)b * rows + r0) * no;
+  const int nflt = nrows * no;
+  for (int i = threadIdx.x; i < nflt; i += 256) tile[i] = src[i];
+  __syncthreads();
+  if ((int)threadIdx.x >= nrows) return;
+  const float* row = tile + threadIdx.x * no;
+  // class max / argmax: first maximum wins, a NaN poisons the result (torch.max semantics)
+  float best = row[5];
+  int arg = 0;
+  bool all_finite = finite_f(best);
+  for (int k = 1; k < no - 5; ++k) {
+    const float v = row[5 + k];
+    all_finite = all_finite && finite_f(v);
+    if (v > best || (v != v && best == best)) {
+      best = v;
+      arg = k;
+    }
+  }
+  const float conf = row[4] * best;                                              // utils.py:213
+  if (mutate) src[threadIdx.x * no + 4] = conf;
+  const float bw = row[2], bh = row[3];
+  all_finite = all_finite && finite_f(row[0]) && finite_f(row[1]) && finite_f(bw) && finite_f(bh) && finite_f(conf);
+  const bool keep = (conf > conf_thres) && (bw > min_wh) && (bh > min_wh) && all_finite;  // :216-218
+  if (keep) {
+    const int pos = atomicAdd(&counts[b], 1);
+    keys[(long)b * key_pitch + pos] = make_key(arg, conf, r0 + threadIdx.x);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+__device__ void block_bitonic_sort(u64* keys, int n_pad) {
+  for (int k = 2; k <= n_pad; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < (n_pad >> 1); t += kMergeThreads) {
+        const int i = ((t / j) * (j << 1)) + (t % j);
+        const int l = i + j;
+        const bool up = (i & k) == 0;
+        const u64 a = keys[i], c = keys[l];
+        if ((a > c) == up) {
+          keys[i] = c;
+          keys[l] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+struct MergeArgs {
+  const float* pred;
+  u64* keys;          // [bs][rows] survivors from the filter (sorted in place when they exceed LDS)
+  const int* counts;  // [bs]
+  float* stage;       // [bs][stage_cap][8] unsorted kept rows (x1,y1,x2,y2,conf,cls_conf,cls,row bits)
+  float* out_dets;    // [bs][cap][7]
+  int* out_idx;       // [bs][cap]
+  int* out_count;     // [bs]
+  int rows, no, nc, max_per_class, cap, stage_cap;
+  long key_pitch;     // keys per image row of the workspace (power of two >= rows)
+  float nms_thres;
+};
+
+__global__ __launch_bounds__(kMergeThreads) void nms_merge_kernel(const MergeArgs a) {
+  __shared__ __attribute__((aligned(16))) u64 s_keys[kLdsKeys];
+  __shared__ int s_seg_start[kMaxClasses];
+  __shared__ int s_seg_len[kMaxClasses];
+  __shared__ float s_box[kMergeWaves][kMaxPerClassCap][5];  // x1,y1,x2,y2,conf per candidate
+  __shared__ int s_nout;
+
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = min(a.counts[b], a.rows);
+  if (n == 0) {
+    if (tid == 0) a.out_count[b] = 0;
+    return;
+  }
+  int n_pad = 1;
+  while (n_pad < n) n_pad <<= 1;
+  u64* gkeys = a.keys + (long)b * a.key_pitch;
+  u64* keys;
+  if (n_pad <= kLdsKeys) {
+    keys = s_keys;
+    for (int i = tid; i < n_pad; i += kMergeThreads) keys[i] = i < n ? gkeys[i] : ~0ull;
+  } else {
+    keys = gkeys;  // the workspace row is sized to a power of two >= rows
+    for (int i = n + tid; i < n_pad; i += kMergeThreads) keys[i] = ~0ull;
+  }
+  for (int c = tid; c < a.nc; c += kMergeThreads) s_seg_len[c] = 0;
+  if (tid == 0) s_nout = 0;
+  __syncthreads();
+  block_bitonic_sort(keys, n_pad);
+
+  // class segments of the sorted list
+  for (int i = tid; i < n; i += kMergeThreads) {
+    const int c = key_class(keys[i]);
+    if (i == 0 || key_class(keys[i - 1]) != c) s_seg_start[c] = i;
+    if (i == n - 1 || key_class(keys[i + 1]) != c) s_seg_len[c] = i + 1;  // end for now
+  }
+  __syncthreads();
+
+  float* stage = a.stage + (long)b * a.stage_cap * 8;
+  const float* pred = a.pred + (long)b * a.rows * a.no;
+  float(*box)[5] = s_box[wave];
+
+  for (int c = wave; c < a.nc; c += kMergeWaves) {
+    const int end = s_seg_len[c];
+    if (end == 0) continue;
+    const int start = s_seg_start[c];
+    const int seg_n = end - start;
+    const int m = min(seg_n, a.max_per_class);                          // utils.py:247-250
+    // gather my (up to two) candidates: xywh -> xyxy (utils.py:57-60)
+    int my_row[2] = {0, 0};
+    float my_cconf[2] = {0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int q = lane + 64 * h;
+      if (q < m) {
+        const u64 k = keys[start + q];
+        const int r = key_row(k);
+        const float* pr = pred + (long)r * a.no;
+        const float x = pr[0], y = pr[1], w = pr[2], hh = pr[3];
+        box[q][0] = x - w / 2.f;
+        box[q][1] = y - hh / 2.f;
+        box[q][2] = x + w / 2.f;
+        box[q][3] = y + hh / 2.f;
+        box[q][4] = key_conf(k);
+        my_row[h] = r;
+        my_cconf[h] = pr[5 + c];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    u64 alive0 = (m >= 64) ? ~0ull : ((1ull << m) - 1ull);
+    u64 alive1 = (m > 64) ? ((m - 64 >= 64) ? ~0ull : ((1ull << (m - 64)) - 1ull)) : 0ull;
+    while (alive0 | alive1) {
+      const int p = alive0 ? __builtin_ctzll(alive0) : 64 + __builtin_ctzll(alive1);
+      const bool last = (__builtin_popcountll(alive0) + __builtin_popcountll(alive1)) == 1;
+      const float px1 = box[p][0], py1 = box[p][1], px2 = box[p][2], py2 = box[p][3];
+      float mx1 = px1, my1 = py1, mx2 = px2, my2 = py2;
+      u64 h0 = 0, h1 = 0;
+      if (last) {                                                        // :268-270 kept as is
+        if (p < 64) h0 = 1ull << p; else h1 = 1ull << (p - 64);
+      } else {
+        bool hit[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int q = lane + 64 * h;
+          const bool live = ((h ? alive1 : alive0) >> lane) & 1ull;
+          hit[h] = false;
+          if (live) {                                                    // bbox_iou, utils.py:85-96
+            const float qx1 = box[q][0], qy1 = box[q][1], qx2 = box[q][2], qy2 = box[q][3];
+            const float iw = fminf(px2, qx2) - fmaxf(px1, qx1);
+            const float ih = fminf(py2, qy2) - fmaxf(py1, qy1);
+            const float inter = fmaxf(iw, 0.f) * fmaxf(ih, 0.f);
+            const float area1 = (px2 - px1) * (py2 - py1) + 1e-16f;
+            const float area2 = (qx2 - qx1) * (qy2 - qy1);
+            const float uni = (area1 + area2) - inter;
+            hit[h] = __fdiv_rn(inter, uni) > a.nms_thres;                // :271
+          }
+        }
+        h0 = __ballot(hit[0]);
+        h1 = __ballot(hit[1]);
+        // weighted mixture box (:272-274), sequential fp32 in candidate order
+        float wsum = 0.f, ax1 = 0.f, ay1 = 0.f, ax2 = 0.f, ay2 = 0.f;
+        u64 w0 = h0, w1 = h1;
+        while (w0 | w1) {
+          int g;
+          if (w0) { g = __builtin_ctzll(w0); w0 &= w0 - 1; }
+          else    { g = 64 + __builtin_ctzll(w1); w1 &= w1 - 1; }
+          const float s = box[g][4];
+          wsum = wsum + s;
+          ax1 = ax1 + s * box[g][0];
+          ay1 = ay1 + s * box[g][1];
+          ax2 = ax2 + s * box[g][2];
+          ay2 = ay2 + s * box[g][3];
+        }
+        mx1 = __fdiv_rn(ax1, wsum);
+        my1 = __fdiv_rn(ay1, wsum);
+        mx2 = __fdiv_rn(ax2, wsum);
+        my2 = __fdiv_rn(ay2, wsum);
+        if ((h0 | h1) == 0) {  // pivot does not overlap itself (the reference would spin forever): drop it
+          if (p < 64) h0 = 1ull << p; else h1 = 1ull << (p - 64);
+        }
+      }
+      // the lane that owns the pivot emits the row
+      if (lane == (p & 63)) {
+        const int hsel = p >> 6;
+        const int slot = atomicAdd(&s_nout, 1);
+        if (slot < a.stage_cap) {
+          float* o = stage + (long)slot * 8;
+          o[0] = mx1; o[1] = my1; o[2] = mx2; o[3] = my2;
+          o[4] = box[p][4];
+          o[5] = hsel ? my_cconf[1] : my_cconf[0];
+          o[6] = (float)c;
+          o[7] = __int_as_float(hsel ? my_row[1] : my_row[0]);
+        }
+      }
+      alive0 &= ~h0;
+      alive1 &= ~h1;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+
+  // ---- final order: conf descending, ties by class then pivot order (utils.py:289-291) -------------
+  const int n_out = min(s_nout, a.stage_cap);
+  __threadfence_block();
+  int f_pad = 1;
+  while (f_pad < n_out) f_pad <<= 1;
+  for (int i = tid; i < f_pad; i += kMergeThreads) {
+    u64 k = ~0ull;
+    if (i < n_out) {
+      const float* o = stage + (long)i * 8;
+      const uint32_t dconf = ~f32_sortable(o[4]);
+      // conf:32 | class:12 | slot:13 (slot order within a class follows pivot order because each
+      // class is emitted by one wave in sequence)  -> compare on conf, class first; slot breaks ties
+      k = ((u64)dconf << 32) | ((u64)(uint32_t)o[6] << 20) | (u64)i;
+    }
+    s_keys[i] = k;
+  }
+  __syncthreads();
+  block_bitonic_sort(s_keys, f_pad);
+  for (int i = tid; i < n_out && i < a.cap; i += kMergeThreads) {
+    const int slot = (int)(s_keys[i] & 0xfffffu);
+    const float* o = stage + (long)slot * 8;
+    float* d = a.out_dets + ((long)b * a.cap + i) * 7;
+#pragma unroll
+    for (int e = 0; e < 7; ++e) d[e] = o[e];
+    a.out_idx[(long)b * a.cap + i] = __float_as_int(o[7]);
+  }
+  if (tid == 0) a.out_count[b] = s_nout;
+}
+
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+inline size_t pow2_at_least(size_t v) {
+  size_t p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+inline int stage_cap_for(int rows, int nc, int max_per_class) {
+  long c = (long)nc * max_per_class;
+  if (c > rows) c = rows;
+  if (c > kLdsKeys) c = kLdsKeys;
+  return (int)c;
+}
+
+}  // namespace
+
+extern "C" size_t yolo_nms_workspace_bytes(int bs, int rows, int nc) {
+  if (bs <= 0 || rows <= 0 || nc <= 0) return 0;
+  const size_t counts = align256((size_t)bs * 4);
+  const size_t keys = align256((size_t)bs * pow2_at_least((size_t)rows) * 8);
+  const size_t stage = align256((size_t)bs * stage_cap_for(rows, nc, kMaxPerClassCap) * 8 * 4);
+  return counts + keys + stage;
+}
+
+extern "C" int yolo_nms_merge(float* pred, int bs, int rows, int nc, float conf_thres, float nms_thres, float min_wh,
+                              int max_per_class, int mutate_conf, float* out_dets, int32_t* out_idx, int32_t* out_count,
+                              int cap, void* workspace, size_t workspace_bytes, yolo_stream_t s) {
+  YOLO_REQUIRE(pred && out_dets && out_idx && out_count && workspace, "nms: null pointer");
+  YOLO_REQUIRE(bs > 0 && rows > 0 && nc > 0 && cap > 0, "nms: bad sizes");
+  YOLO_REQUIRE(nc <= kMaxClasses, "nms: n_class %d > %d unsupported", nc, kMaxClasses);
+  YOLO_REQUIRE(rows < (1 << 20), "nms: rows %d >= 2^20 unsupported", rows);
+  YOLO_REQUIRE(max_per_class >= 1 && max_per_class <= kMaxPerClassCap, "nms: max_per_class %d not in [1,%d]", max_per_class,
+               kMaxPerClassCap);
+  YOLO_REQUIRE(nms_thres < 1.f, "nms: nms_thres must be < 1 (the reference never terminates otherwise)");
+  const int no = nc + 5;
+  const size_t tile_bytes = (size_t)kFilterRows * no * 4;
+  YOLO_REQUIRE(tile_bytes <= 64 * 1024, "nms: row of %d floats too wide", no);
+  if (workspace_bytes < yolo_nms_workspace_bytes(bs, rows, nc))
+    return yolo_set_error(YOLO_E_WORKSPACE, "nms: workspace %zu < %zu bytes", workspace_bytes,
+                          yolo_nms_workspace_bytes(bs, rows, nc));
+  hipStream_t st = (hipStream_t)s;
+  char* ws = (char*)workspace;
+  int* counts = (int*)ws;
+  ws += align256((size_t)bs * 4);
+  const size_t row_keys = pow2_at_least((size_t)rows);
+  u64* keys = (u64*)ws;
+  ws += align256((size_t)bs * row_keys * 8);
+  float* stage = (float*)ws;
+
+  hipError_t e = hipMemsetAsync(counts, 0, align256((size_t)bs * 4), st);
+  if (e != hipSuccess) return yolo_set_error((int)e, "nms: memset: %s", hipGetErrorString(e));
+  dim3 fgrid((unsigned)((rows + kFilterRows - 1) / kFilterRows), (unsigned)bs);
+  hipLaunchKernelGGL(nms_filter_kernel, fgrid, dim3(256), tile_bytes, st, pred, rows, no, conf_thres, min_wh, mutate_conf,
+                     keys, (long)row_keys, counts);
+  int rc = yolo_check_launch("yolo_nms_merge(filter)");
+  if (rc) return rc;
+  MergeArgs a;
+  a.pred = pred;
+  a.keys = keys;
+  a.counts = counts;
+  a.stage = stage;
+  a.out_dets = out_dets;
+  a.out_idx = out_idx;
+  a.out_count = out_count;
+  a.rows = rows;
+  a.key_pitch = (long)row_keys;
+  a.no = no;
+  a.nc = nc;
+  a.max_per_class = max_per_class;
+  a.cap = cap;
+  a.stage_cap = stage_cap_for(rows, nc, kMaxPerClassCap);
+  a.nms_thres = nms_thres;
+  hipLaunchKernelGGL(nms_merge_kernel, dim3((unsigned)bs), dim3(kMergeThreads), 0, st, a);
+  return yolo_check_launch("yolo_nms_merge(merge)");
+}

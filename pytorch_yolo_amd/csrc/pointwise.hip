@@ -1,0 +1,281 @@
+// HBM-bound element kernels of the path (gfx950): input packing, max pools / SPP pyramid,
+// depthwise 3x3, YOLO-layer decode.  All are coalesced 16-byte-per-lane streams over NHWC data.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// NCHW f32 -> NHWC bf16, channels padded with zeros (first-layer layout).
+__global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int c,
+                                                         long hw, long total_pix, int c_pad) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= total_pix) return;
+  const long b = p / hw, sp = p - b * hw;
+  const float* src = x + b * c * hw + sp;
+  bf16_t* dst = y + p * c_pad;
+  for (int c0 = 0; c0 < c_pad; c0 += 8) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((c0 + e < c) ? src[(long)(c0 + e) * hw] : 0.f);
+    *reinterpret_cast<bf16x8*>(dst + c0) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16x8 lane-wise max (bf16 -> f32 widening is exact, so comparing as f32 and keeping the bits is exact)
+__device__ __forceinline__ void max8(float (&m)[8], const u32x4 v) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    m[2 * e] = fmaxf(m[2 * e], __uint_as_float(v[e] << 16));
+    m[2 * e + 1] = fmaxf(m[2 * e + 1], __uint_as_float(v[e] & 0xffff0000u));
+  }
+}
+__device__ __forceinline__ u32x4 pack8(const float (&m)[8]) {
+  u32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (__float_as_uint(m[2 * e]) >> 16) | (__float_as_uint(m[2 * e + 1]) & 0xffff0000u);
+  return o;
+}
+
+// Generic max pool, -inf padding (nn.MaxPool2d semantics), one thread = 8 channels of one output pixel.
+__global__ __launch_bounds__(256) void maxpool_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int h, int w,
+                                                      int cg, int in_ct, int in_co, int ho, int wo, int out_ct, int out_co,
+                                                      int k, int stride, int pad, int dil, long total) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int g = (int)(t % cg);
+  long p = t / cg;
+  const int ow = (int)(p % wo);
+  p /= wo;
+  const int oh = (int)(p % ho);
+  const long b = p / ho;
+  float m[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+  for (int i = 0; i < k; ++i) {
+    const int hi = oh * stride - pad + i * dil;
+    if ((unsigned)hi >= (unsigned)h) continue;
+    for (int j = 0; j < k; ++j) {
+      const int wi = ow * stride - pad + j * dil;
+      if ((unsigned)wi >= (unsigned)w) continue;
+      max8(m, *reinterpret_cast<const u32x4*>(x + ((b * h + hi) * w + wi) * in_ct + in_co + g * 8));
+    }
+  }
+  *reinterpret_cast<u32x4*>(y + ((b * ho + oh) * wo + ow) * out_ct + out_co + g * 8) = pack8(m);
+}
+
+// SPP pyramid: one block = one image x 8 channels; the hxw plane lives in LDS; separable running max
+// (rows then columns) gives 5/9/13 windows in one pass.  Reads slice [3c,4c) of the concat buffer,
+// writes slices [0,c) [c,2c) [2c,3c).
+__global__ __launch_bounds__(256) void spp_kernel(bf16_t* __restrict__ buf, int h, int w, int c) {
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  u32x4* plane = reinterpret_cast<u32x4*>(lds_raw);  // [h*w] input, then 3 x [h*w] row-maxima
+  const int hw = h * w, ct = 4 * c;
+  const int cg = c / 8;
+  const long b = blockIdx.x / cg;
+  const int g = blockIdx.x % cg;
+  bf16_t* base = buf + b * hw * ct + g * 8;
+  for (int p = threadIdx.x; p < hw; p += 256) plane[p] = *reinterpret_cast<const u32x4*>(base + (long)p * ct + 3 * c);
+  __syncthreads();
+  for (int p = threadIdx.x; p < hw; p += 256) {
+    const int yy = p / w, xx = p - yy * w;
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+    max8(m, plane[p]);
+    for (int r = 1; r <= 6; ++r) {
+      if (xx - r >= 0) max8(m, plane[p - r]);
+      if (xx + r < w) max8(m, plane[p + r]);
+      if (r == 2) plane[hw + p] = pack8(m);
+      if (r == 4) plane[2 * hw + p] = pack8(m);
+    }
+    plane[3 * hw + p] = pack8(m);
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < hw; p += 256) {
+    const int yy = p / w;
+#pragma unroll
+    for (int lvl = 0; lvl < 3; ++lvl) {
+      const int rad = 2 + 2 * lvl;
+      const u32x4* rows = plane + (lvl + 1) * hw;
+      float m[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+      for (int r = -rad; r <= rad; ++r)
+        if ((unsigned)(yy + r) < (unsigned)h) max8(m, rows[p + r * w]);
+      *reinterpret_cast<u32x4*>(base + (long)p * ct + lvl * c) = pack8(m);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Depthwise 3x3 (pad 1) + bias + activation, one thread = 8 channels of one output pixel, fp32 math.
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const bf16_t* __restrict__ x, const float* __restrict__ wt,
+                                                        const float* __restrict__ bias, bf16_t* __restrict__ y, int h, int w,
+                                                        int c, int in_ct, int in_co, int ho, int wo, int out_ct, int out_co,
+                                                        int stride, int act, long total) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int cg = c / 8;
+  const int g = (int)(t % cg);
+  long p = t / cg;
+  const int ow = (int)(p % wo);
+  p /= wo;
+  const int oh = (int)(p % ho);
+  const long b = p / ho;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = bias[g * 8 + e];
+  for (int i = 0; i < 3; ++i) {
+    const int hi = oh * stride - 1 + i;
+    if ((unsigned)hi >= (unsigned)h) continue;
+    for (int j = 0; j < 3; ++j) {
+      const int wi = ow * stride - 1 + j;
+      if ((unsigned)wi >= (unsigned)w) continue;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(x + ((b * h + hi) * w + wi) * in_ct + in_co + g * 8);
+      const float* wp = wt + (i * 3 + j) * c + g * 8;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[2 * e] = fmaf(__uint_as_float(v[e] << 16), wp[2 * e], acc[2 * e]);
+        acc[2 * e + 1] = fmaf(__uint_as_float(v[e] & 0xffff0000u), wp[2 * e + 1], acc[2 * e + 1]);
+      }
+    }
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float v = acc[e];
+    if (act == YOLO_ACT_LEAKY01) v = v > 0.f ? v : 0.1f * v;
+    if (act == YOLO_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+    o[e] = (bf16_t)v;
+  }
+  *reinterpret_cast<bf16x8*>(y + ((b * ho + oh) * wo + ow) * out_ct + out_co + g * 8) = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// YOLOLayer decode (reference models/yolo_layer.py:57-69,90-111).  Thread t <-> element t of
+// p[bs,na,ny,nx,5+nc] (so the p and io stores are fully contiguous); the head read is contiguous
+// within each (5+nc)-run because the head is NHWC with channel a*(5+nc)+k.
+struct DecodeArgs {
+  const float* head;
+  float* io;
+  float* p;
+  int head_ct, na, nc, ny, nx, io_rows_total, io_row_offset;
+  float stride;
+  float anchor_w[8], anchor_h[8];  // anchors / stride (yolo_layer.py:109)
+  long total;
+};
+
+__global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= a.total) return;
+  const int no = a.nc + 5;
+  const int k = (int)(t % no);
+  long cell = t / no;
+  const int gx = (int)(cell % a.nx);
+  cell /= a.nx;
+  const int gy = (int)(cell % a.ny);
+  cell /= a.ny;
+  const int an = (int)(cell % a.na);
+  const long b = cell / a.na;
+  const float raw = a.head[((b * a.ny + gy) * a.nx + gx) * a.head_ct + an * no + k];
+  if (a.p) a.p[t] = raw;
+  float v;
+  if (k < 2) {
+    v = (1.f / (1.f + expf(-raw)) + (float)(k == 0 ? gx : gy)) * a.stride;   // :91,:94
+  } else if (k < 4) {
+    v = (expf(raw) * (k == 2 ? a.anchor_w[an] : a.anchor_h[an])) * a.stride;  // :92,:94
+  } else {
+    v = 1.f / (1.f + expf(-raw));                                             // :93
+    if (a.nc == 1 && k == 5) v = 1.f;                                         // :95-96
+  }
+  const long row = a.io_row_offset + ((long)an * a.ny + gy) * a.nx + gx;
+  a.io[(b * a.io_rows_total + row) * no + k] = v;
+}
+
+inline unsigned blocks_for(long total) { return (unsigned)((total + 255) / 256); }
+
+}  // namespace
+
+extern "C" int yolo_pack_input_nchw_f32(const float* x, void* y, int n, int c, int h, int w, int c_pad, yolo_stream_t s) {
+  YOLO_REQUIRE(x && y && n > 0 && c > 0 && h > 0 && w > 0, "pack_input: bad arguments");
+  YOLO_REQUIRE(c_pad % 8 == 0 && c_pad >= c, "pack_input: c_pad %d must be a multiple of 8 and >= c %d", c_pad, c);
+  const long total = (long)n * h * w;
+  hipLaunchKernelGGL(pack_input_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)s, x, (bf16_t*)y, c,
+                     (long)h * w, total, c_pad);
+  return yolo_check_launch("yolo_pack_input_nchw_f32");
+}
+
+extern "C" int yolo_maxpool_fwd(const void* x, void* y, int n, int h, int w, int c, int in_c_total, int in_c_offset, int ho,
+                                int wo, int out_c_total, int out_c_offset, int ksize, int stride, int pad, int dilation,
+                                yolo_stream_t s) {
+  YOLO_REQUIRE(x && y && n > 0 && c > 0 && c % 8 == 0, "maxpool: bad arguments (c %d must be a multiple of 8)", c);
+  YOLO_REQUIRE(in_c_total % 8 == 0 && in_c_offset % 8 == 0 && out_c_total % 8 == 0 && out_c_offset % 8 == 0,
+               "maxpool: views must be 8-channel aligned");
+  YOLO_REQUIRE(ksize >= 1 && stride >= 1 && dilation >= 1 && pad >= 0, "maxpool: bad geometry");
+  YOLO_REQUIRE(ho == (h + 2 * pad - dilation * (ksize - 1) - 1) / stride + 1 &&
+                   wo == (w + 2 * pad - dilation * (ksize - 1) - 1) / stride + 1,
+               "maxpool: output %dx%d inconsistent with %dx%d k%d s%d p%d d%d", ho, wo, h, w, ksize, stride, pad, dilation);
+  const long total = (long)n * ho * wo * (c / 8);
+  hipLaunchKernelGGL(maxpool_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (bf16_t*)y, h,
+                     w, c / 8, in_c_total, in_c_offset, ho, wo, out_c_total, out_c_offset, ksize, stride, pad, dilation, total);
+  return yolo_check_launch("yolo_maxpool_fwd");
+}
+
+extern "C" int yolo_spp_fwd(void* buf, int n, int h, int w, int c, yolo_stream_t s) {
+  YOLO_REQUIRE(buf && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0, "spp: bad arguments");
+  const size_t lds = (size_t)4 * h * w * 16;
+  if (lds <= 64 * 1024) {
+    hipLaunchKernelGGL(spp_kernel, dim3((unsigned)(n * (c / 8))), dim3(256), lds, (hipStream_t)s, (bf16_t*)buf, h, w, c);
+    return yolo_check_launch("yolo_spp_fwd");
+  }
+  // large feature maps: three direct pools (same results, more L2 traffic)
+  for (int lvl = 0; lvl < 3; ++lvl) {
+    const int k = 5 + 4 * lvl;
+    int rc = yolo_maxpool_fwd(buf, buf, n, h, w, c, 4 * c, 3 * c, h, w, 4 * c, lvl * c, k, 1, k / 2, 1, s);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+extern "C" int yolo_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int n, int h, int w_, int c,
+                                  int in_c_total, int in_c_offset, int ho, int wo, int out_c_total, int out_c_offset,
+                                  int stride, int act, yolo_stream_t s) {
+  YOLO_REQUIRE(x && w && bias && y && n > 0 && c > 0 && c % 8 == 0, "dwconv: bad arguments");
+  YOLO_REQUIRE(stride == 1 || stride == 2, "dwconv: stride %d", stride);
+  YOLO_REQUIRE(ho == (h + 2 - 3) / stride + 1 && wo == (w_ + 2 - 3) / stride + 1, "dwconv: bad output size");
+  YOLO_REQUIRE(in_c_total % 8 == 0 && in_c_offset % 8 == 0 && out_c_total % 8 == 0 && out_c_offset % 8 == 0,
+               "dwconv: views must be 8-channel aligned");
+  const long total = (long)n * ho * wo * (c / 8);
+  hipLaunchKernelGGL(dwconv3x3_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, w, bias,
+                     (bf16_t*)y, h, w_, c, in_c_total, in_c_offset, ho, wo, out_c_total, out_c_offset, stride, act, total);
+  return yolo_check_launch("yolo_dwconv3x3_fwd");
+}
+
+extern "C" int yolo_decode_fwd(const float* head, int head_c_total, const float* anchors_px, int na, int nc, int bs, int ny,
+                               int nx, float stride_px, float* io, int io_rows_total, int io_row_offset, float* p,
+                               yolo_stream_t s) {
+  YOLO_REQUIRE(head && anchors_px && io, "decode: null pointer");
+  YOLO_REQUIRE(na >= 1 && na <= 8 && nc >= 1 && bs > 0 && ny > 0 && nx > 0, "decode: bad sizes");
+  YOLO_REQUIRE(head_c_total >= na * (5 + nc), "decode: head_c_total %d < %d", head_c_total, na * (5 + nc));
+  YOLO_REQUIRE(io_row_offset >= 0 && io_row_offset + na * ny * nx <= io_rows_total, "decode: rows out of range");
+  DecodeArgs a;
+  a.head = head;
+  a.io = io;
+  a.p = p;
+  a.head_ct = head_c_total;
+  a.na = na;
+  a.nc = nc;
+  a.ny = ny;
+  a.nx = nx;
+  a.io_rows_total = io_rows_total;
+  a.io_row_offset = io_row_offset;
+  a.stride = stride_px;
+  for (int i = 0; i < na; ++i) {
+    a.anchor_w[i] = anchors_px[2 * i] / stride_px;
+    a.anchor_h[i] = anchors_px[2 * i + 1] / stride_px;
+  }
+  a.total = (long)bs * na * ny * nx * (5 + nc);
+  hipLaunchKernelGGL(decode_kernel, dim3(blocks_for(a.total)), dim3(256), 0, (hipStream_t)s, a);
+  return yolo_check_launch("yolo_decode_fwd");
+}

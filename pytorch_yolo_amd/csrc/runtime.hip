@@ -1,0 +1,46 @@
+// Error reporting, ABI version and the batched launcher of libyolo_hip.so.
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+int yolo_set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+extern "C" const char* yolo_last_error(void) { return g_err; }
+extern "C" int yolo_abi_version(void) { return 1; }
+
+// One FFI crossing for a whole recorded layer list: the forward pass is ~80 launches, and at
+// ~3 us of Python/ctypes per call the host would otherwise be a visible fraction of a 5 ms batch.
+extern "C" int yolo_run_ops(const YoloOp* ops, int n_ops, yolo_stream_t s) {
+  YOLO_REQUIRE(ops || n_ops == 0, "run_ops: null op list");
+  for (int i = 0; i < n_ops; ++i) {
+    const YoloOp& o = ops[i];
+    const YoloConvDesc& d = o.conv;
+    int rc;
+    switch (o.kind) {
+      case YOLO_OP_CONV:
+        rc = yolo_conv2d_launch(o.x, o.w, o.bias, o.residual, o.y, o.y_aux, &d, (hipStream_t)s);
+        break;
+      case YOLO_OP_MAXPOOL:
+        rc = yolo_maxpool_fwd(o.x, o.y, d.n, d.h, d.w, d.cin, d.in_c_total, d.in_c_offset, d.ho, d.wo, d.out_c_total,
+                              d.out_c_offset, d.ksize, d.stride, d.pad, d.upsample2x /* dilation */, s);
+        break;
+      case YOLO_OP_SPP:
+        rc = yolo_spp_fwd(o.y, d.n, d.h, d.w, d.cin, s);
+        break;
+      case YOLO_OP_DWCONV:
+        rc = yolo_dwconv3x3_fwd(o.x, (const float*)o.w, o.bias, o.y, d.n, d.h, d.w, d.cin, d.in_c_total, d.in_c_offset, d.ho,
+                                d.wo, d.out_c_total, d.out_c_offset, d.stride, d.act, s);
+        break;
+      default:
+        return yolo_set_error(YOLO_E_ARG, "run_ops: op %d has unknown kind %d", i, o.kind);
+    }
+    if (rc) return rc;
+  }
+  return 0;
+}

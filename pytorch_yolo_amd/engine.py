@@ -1,0 +1,380 @@
+"""Layer-graph recorder, placement planner and executor for the HIP path.
+
+A model describes its forward once, symbolically, through ``Recorder`` (the
+model's ``_trace`` method reads like the reference's ``_forward_encoder``).
+``Plan`` then decides where every activation lives so that the reference's
+element-wise glue disappears into the convolution epilogues:
+
+* ``Concat`` (reference models/yolo_layer.py:16-22): every input is produced
+  straight into its channel slice of one NHWC buffer;
+* ``Upsample(2)`` (:6-13): folded into the producing conv's store (2x2 replicate);
+* ``Add`` (models/yolov3_spp.py:12-14): residual read in the conv epilogue,
+  written in place of the residual input; the pre-add branch output the
+  reference routes to the FPN (yolov3_spp.py:42-46) is a second epilogue store;
+* SPP ``cat([p5,p9,p13,x])`` (yolov3_spp.py:129): conv writes x into the last
+  slice, one kernel fills the other three.
+
+Execution is one ``yolo_run_ops`` FFI call for all layers + one decode launch
+per head, optionally captured in a HIP graph.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+
+from . import kernels as K
+from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU6, DT_BF16, DT_F32, OP_CONV, OP_DWCONV,
+                   OP_MAXPOOL, OP_SPP, YoloOp)
+
+
+# ------------------------------------------------------------------------------------------------
+# symbolic graph
+@dataclass(eq=False)
+class Sym:
+    """A logical NHWC activation."""
+    n: int
+    h: int
+    w: int
+    c: int
+    producer: Optional["Node"] = None
+    slot: int = 0                      # 0 main output, 1 pre-add output
+    f32: bool = False
+    # placement (filled by the planner)
+    buf: Optional["Buf"] = None
+    c_offset: int = 0
+    consumers: List["Node"] = field(default_factory=list)
+
+
+@dataclass(eq=False)
+class Buf:
+    n: int
+    h: int
+    w: int
+    c_total: int
+    f32: bool = False
+    tensor: Optional[torch.Tensor] = None
+
+
+@dataclass(eq=False)
+class Node:
+    kind: str                          # input | conv | dwconv | pool | spp | up | cat | head
+    srcs: List[Sym]
+    outs: List[Sym]
+    attrs: dict
+
+
+class Recorder:
+    def __init__(self, n, c_in, h, w):
+        self.nodes: List[Node] = []
+        self.c_in = c_in
+        x = Sym(n, h, w, K.roundup(c_in, 8))
+        self.input = x
+        self._add("input", [], [x])
+        self.heads = []
+
+    def _add(self, kind, srcs, outs, **attrs):
+        node = Node(kind, list(srcs), list(outs), attrs)
+        for o in outs:
+            o.producer = node
+        for s in srcs:
+            s.consumers.append(node)
+        self.nodes.append(node)
+        return node
+
+    # weight = (w_oihw f32, bias f32) already BN-folded; act in {'leaky','relu6','none'}
+    def conv(self, x: Sym, weight, stride=1, act="leaky", residual: Sym = None, want_preadd=False, f32_out=False):
+        w, _ = weight
+        cout, cin_w, k, _ = w.shape
+        if cin_w > x.c:
+            raise RuntimeError(f"conv expects {cin_w} input channels, tensor has {x.c}")
+        pad = (k - 1) // 2
+        ho, wo = (x.h + 2 * pad - k) // stride + 1, (x.w + 2 * pad - k) // stride + 1
+        if not f32_out and cout % 8:
+            raise RuntimeError(f"internal conv width {cout} is not a multiple of 8 (unsupported kernels_divider)")
+        y = Sym(x.n, ho, wo, cout, f32=f32_out)
+        outs = [y]
+        if want_preadd:
+            outs.append(Sym(x.n, ho, wo, cout, slot=1))
+        srcs = [x] + ([residual] if residual is not None else [])
+        self._add("conv", srcs, outs, weight=weight, stride=stride, act=act, has_res=residual is not None)
+        return (y, outs[1]) if want_preadd else y
+
+    def dwconv(self, x: Sym, weight, stride=1, act="relu6"):
+        w, _ = weight                                   # [c,1,3,3]
+        ho, wo = (x.h - 1) // stride + 1, (x.w - 1) // stride + 1
+        y = Sym(x.n, ho, wo, x.c)
+        self._add("dwconv", [x], [y], weight=weight, stride=stride, act=act)
+        return y
+
+    def maxpool(self, x: Sym, size, stride):
+        # reference MaxPool: (2,1) -> pad 1, dilation 2 (models/yolo_base.py:60-66)
+        if size == 2 and stride == 1:
+            pad, dil = 1, 2
+        else:
+            pad, dil = (size - 1) // 2, 1
+        ho = (x.h + 2 * pad - dil * (size - 1) - 1) // stride + 1
+        wo = (x.w + 2 * pad - dil * (size - 1) - 1) // stride + 1
+        y = Sym(x.n, ho, wo, x.c)
+        self._add("pool", [x], [y], size=size, stride=stride, pad=pad, dil=dil)
+        return y
+
+    def spp_concat(self, x: Sym):
+        y = Sym(x.n, x.h, x.w, 4 * x.c)
+        self._add("spp", [x], [y])
+        return y
+
+    def upsample2(self, x: Sym):
+        y = Sym(x.n, 2 * x.h, 2 * x.w, x.c)
+        self._add("up", [x], [y])
+        return y
+
+    def concat(self, xs: List[Sym]):
+        y = Sym(xs[0].n, xs[0].h, xs[0].w, sum(x.c for x in xs))
+        self._add("cat", xs, [y])
+        return y
+
+    def head(self, x: Sym, yolo_layer):
+        self.heads.append((x, yolo_layer))
+        self._add("head", [x], [])
+
+
+_ACT = {"leaky": ACT_LEAKY01, "relu6": ACT_RELU6, "none": ACT_NONE}
+
+
+# ------------------------------------------------------------------------------------------------
+class Plan:
+    """Buffers + packed weights + launch list for one (batch, H, W) on one device."""
+
+    def __init__(self, rec: Recorder, device, n_class: int, img_size: int):
+        self.device = device
+        self.rec = rec
+        self.n_class = n_class
+        self.img_size = img_size
+        self._bufs: List[Buf] = []
+        self._keep = []                 # packed weights / biases kept alive
+        self._place()
+        self._alloc()
+        self._build_ops()
+        self._graph = None
+        self._static_out = None
+
+    # -- placement ---------------------------------------------------------------------------------
+    def _new_buf(self, s: Sym, c_total=None) -> Buf:
+        b = Buf(s.n, s.h, s.w, c_total or s.c, f32=s.f32)
+        self._bufs.append(b)
+        return b
+
+    def _place(self):
+        nodes = self.rec.nodes
+        order = {id(nd): i for i, nd in enumerate(nodes)}
+        # 1. concat / spp outputs own a buffer; their inputs are placed into slices of it
+        for nd in nodes:
+            if nd.kind == "cat":
+                y = nd.outs[0]
+                if y.buf is None:
+                    y.buf, y.c_offset = self._new_buf(y), 0
+                off = y.c_offset
+                for x in nd.srcs:
+                    if x.buf is not None:
+                        raise RuntimeError("a tensor feeds two concats: needs a copy (not required by any model here)")
+                    x.buf, x.c_offset = y.buf, off
+                    off += x.c
+            elif nd.kind == "spp":
+                y, x = nd.outs[0], nd.srcs[0]
+                if y.buf is None:
+                    y.buf, y.c_offset = self._new_buf(y), 0
+                if y.c_offset != 0 or y.buf.c_total != y.c:
+                    raise RuntimeError("spp output must own its buffer")
+                if x.buf is not None:
+                    raise RuntimeError("spp input already placed")
+                x.buf, x.c_offset = y.buf, 3 * x.c
+        # 2. upsample outputs: the producing conv stores the replicated pixels itself
+        for nd in nodes:
+            if nd.kind == "up":
+                x, y = nd.srcs[0], nd.outs[0]
+                if x.producer.kind != "conv" or len(x.consumers) != 1:
+                    raise RuntimeError("upsample must directly follow a conv with no other consumer")
+                if y.buf is None:
+                    y.buf, y.c_offset = self._new_buf(y), 0
+                x.producer.attrs["up_into"] = y
+        # 3. residual adds are written in place of the residual input when it is dead afterwards
+        for nd in nodes:
+            if nd.kind == "conv" and nd.attrs["has_res"]:
+                res, y = nd.srcs[1], nd.outs[0]
+                dead = all(order[id(cn)] <= order[id(nd)] for cn in res.consumers)
+                if dead and y.buf is None and res.buf is not None and not y.f32:
+                    y.buf, y.c_offset = res.buf, res.c_offset
+                elif dead and y.buf is None and res.buf is None:
+                    nd.attrs["alias_res"] = True
+        # 4. everything else gets its own buffer
+        for nd in nodes:
+            for o in nd.outs:
+                if o.buf is None and not (nd.kind == "conv" and "up_into" in nd.attrs and o.slot == 0):
+                    if nd.kind == "conv" and nd.attrs.get("alias_res") and o.slot == 0:
+                        continue
+                    o.buf, o.c_offset = self._new_buf(o), 0
+        for nd in nodes:      # resolve in-place aliases now that the residual inputs have buffers
+            if nd.kind == "conv" and nd.attrs.get("alias_res"):
+                res, y = nd.srcs[1], nd.outs[0]
+                y.buf, y.c_offset = res.buf, res.c_offset
+
+    def _alloc(self):
+        for b in self._bufs:
+            dt = torch.float32 if b.f32 else torch.bfloat16
+            ct = K.roundup(b.c_total, 8)
+            b.c_total = ct
+            # zero-filled once: padded channels (e.g. 255 -> 256 head rows) are never written
+            b.tensor = torch.zeros((b.n, b.h, b.w, ct), dtype=dt, device=self.device)
+
+    # -- launch list ---------------------------------------------------------------------------------
+    def _dev(self, t):
+        t = t.to(self.device)
+        self._keep.append(t)
+        return t
+
+    def _build_ops(self):
+        ops = []
+        for nd in self.rec.nodes:
+            if nd.kind == "conv":
+                x = nd.srcs[0]
+                y = nd.outs[0]
+                w, b = nd.attrs["weight"]
+                wp, bp, kpad, cout_pad = K.pack_conv_weight(w, b, x.c)
+                wp, bp = self._dev(wp), self._dev(bp)
+                up = nd.attrs.get("up_into")
+                dst = up if up is not None else y
+                res = nd.srcs[1] if nd.attrs["has_res"] else None
+                aux = nd.outs[1] if len(nd.outs) > 1 else None
+                d = K.conv_desc(n=x.n, h=x.h, w=x.w, cin=x.c, in_c_total=x.buf.c_total, in_c_offset=x.c_offset,
+                                cout=w.shape[0], out_c_total=dst.buf.c_total, out_c_offset=dst.c_offset,
+                                ksize=w.shape[2], stride=nd.attrs["stride"], act=_ACT[nd.attrs["act"]],
+                                kpad=kpad, cout_pad=cout_pad, upsample2x=1 if up is not None else 0,
+                                out_dtype=DT_F32 if y.f32 else DT_BF16,
+                                res=(res.buf.c_total, res.c_offset) if res is not None else (0, 0),
+                                aux=(aux.buf.c_total, aux.c_offset) if aux is not None else (0, 0))
+                op = YoloOp()
+                op.kind = OP_CONV
+                op.x, op.w, op.bias = x.buf.tensor.data_ptr(), wp.data_ptr(), bp.data_ptr()
+                op.residual = res.buf.tensor.data_ptr() if res is not None else None
+                op.y = dst.buf.tensor.data_ptr()
+                op.y_aux = aux.buf.tensor.data_ptr() if aux is not None else None
+                op.conv = d
+                ops.append(op)
+            elif nd.kind == "dwconv":
+                x, y = nd.srcs[0], nd.outs[0]
+                w, b = nd.attrs["weight"]
+                w9c = self._dev(w.detach().float().reshape(x.c, 9).t().contiguous())
+                bb = self._dev(b.detach().float().contiguous())
+                op = YoloOp()
+                op.kind = OP_DWCONV
+                op.x, op.w, op.bias, op.y = x.buf.tensor.data_ptr(), w9c.data_ptr(), bb.data_ptr(), y.buf.tensor.data_ptr()
+                d = op.conv
+                d.n, d.h, d.w, d.cin = x.n, x.h, x.w, x.c
+                d.in_c_total, d.in_c_offset, d.ho, d.wo = x.buf.c_total, x.c_offset, y.h, y.w
+                d.out_c_total, d.out_c_offset, d.stride, d.act = y.buf.c_total, y.c_offset, nd.attrs["stride"], _ACT[nd.attrs["act"]]
+                ops.append(op)
+            elif nd.kind == "pool":
+                x, y = nd.srcs[0], nd.outs[0]
+                op = YoloOp()
+                op.kind = OP_MAXPOOL
+                op.x, op.y = x.buf.tensor.data_ptr(), y.buf.tensor.data_ptr()
+                d = op.conv
+                d.n, d.h, d.w, d.cin = x.n, x.h, x.w, x.c
+                d.in_c_total, d.in_c_offset, d.ho, d.wo = x.buf.c_total, x.c_offset, y.h, y.w
+                d.out_c_total, d.out_c_offset = y.buf.c_total, y.c_offset
+                d.ksize, d.stride, d.pad, d.upsample2x = nd.attrs["size"], nd.attrs["stride"], nd.attrs["pad"], nd.attrs["dil"]
+                ops.append(op)
+            elif nd.kind == "spp":
+                x, y = nd.srcs[0], nd.outs[0]
+                op = YoloOp()
+                op.kind = OP_SPP
+                op.y = y.buf.tensor.data_ptr()
+                d = op.conv
+                d.n, d.h, d.w, d.cin = x.n, x.h, x.w, x.c
+                ops.append(op)
+        self.n_ops = len(ops)
+        self.op_array = (YoloOp * len(ops))(*ops)
+        # heads
+        self.heads = []
+        row = 0
+        for x, layer in self.rec.heads:
+            na = len(layer.anchors_px)
+            stride = self.img_size / max(x.w, x.h)          # yolo_layer.py:102 (python float)
+            self.heads.append(dict(sym=x, anchors=layer.anchors_px, stride=stride, row=row, na=na, layer=layer))
+            row += na * x.h * x.w
+        self.rows_total = row
+
+    # -- execution -----------------------------------------------------------------------------------
+    @property
+    def input_buffer(self) -> torch.Tensor:
+        return self.rec.input.buf.tensor
+
+    def _launch(self, x: torch.Tensor, io: torch.Tensor, ps):
+        K.pack_input(x, self.input_buffer)
+        K.run_ops(self.op_array, self.n_ops)
+        for hd, p in zip(self.heads, ps):
+            s = hd["sym"]
+            K.decode(s.buf.tensor, hd["anchors"], self.n_class, hd["stride"], io, hd["row"], p)
+
+    def new_outputs(self):
+        n = self.rec.input.n
+        no = self.n_class + 5
+        io = torch.empty((n, self.rows_total, no), dtype=torch.float32, device=self.device)
+        ps = tuple(torch.empty((n, hd["na"], hd["sym"].h, hd["sym"].w, no), dtype=torch.float32, device=self.device)
+                   for hd in self.heads)
+        return io, ps
+
+    def run(self, x: torch.Tensor):
+        """Eager launch on the current stream; returns fresh (io, p) tensors."""
+        io, ps = self.new_outputs()
+        self._launch(x, io, ps)
+        return io, ps
+
+    def activation_bytes(self) -> int:
+        return sum(b.tensor.numel() * b.tensor.element_size() for b in self._bufs)
+
+    # -- HIP-graph replay ------------------------------------------------------------------------------
+    def run_graph(self, x: torch.Tensor):
+        """Replay the whole forward (pack + layers + decodes) as one captured HIP graph.
+        Returns STATIC output tensors: they are overwritten by the next call."""
+        if self._graph is None:
+            self._static_x = torch.empty_like(x)
+            self._static_out = self.new_outputs()
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                    # warm-up outside capture
+                self._static_x.copy_(x)
+                self._launch(self._static_x, *self._static_out)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._launch(self._static_x, *self._static_out)
+            self._graph = graph
+        self._static_x.copy_(x)
+        self._graph.replay()
+        return self._static_out
+
+
+def _sym_to_nchw(s: Sym) -> torch.Tensor:
+    t = s.buf.tensor[..., s.c_offset:s.c_offset + s.c]
+    return t.permute(0, 3, 1, 2).float().contiguous()
+
+
+def run_standalone(trace_fn, x: torch.Tensor):
+    """Run a recorded sub-graph (a block, a stage) on an NCHW float32 CUDA tensor and return its
+    output(s) as NCHW float32 — used by the block-level ``forward`` methods and their tests."""
+    if not x.is_cuda:
+        raise RuntimeError("pytorch_yolo_amd runs on a ROCm device only (no CPU fallback)")
+    x = x.float().contiguous()
+    bs, c, h, w = x.shape
+    rec = Recorder(bs, c, h, w)
+    out = trace_fn(rec, rec.input)
+    plan = Plan(rec, x.device, n_class=0, img_size=max(h, w))
+    K.pack_input(x, plan.input_buffer)
+    K.run_ops(plan.op_array, plan.n_ops)
+    if isinstance(out, (tuple, list)):
+        return tuple(_sym_to_nchw(s) for s in out)
+    return _sym_to_nchw(out)

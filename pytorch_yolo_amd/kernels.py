@@ -1,0 +1,148 @@
+"""Python-side wrappers of the C-ABI entry points (shape / dtype validation
+happens here, before the FFI crossing — include/yolo_hip.h "Errors").
+
+All tensors are torch CUDA (ROCm) tensors; launches go to the current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU6, DT_BF16, DT_F32, YoloConvDesc,
+                   check, load)
+
+__all__ = ["stream_ptr", "pack_input", "conv2d", "maxpool", "spp", "dwconv3x3", "decode",
+           "nms_merge", "pack_conv_weight", "roundup", "run_ops"]
+
+
+def roundup(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _need_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("pytorch_yolo_amd kernels need tensors on a ROCm device (no CPU fallback)")
+
+
+def pack_conv_weight(w_oihw: torch.Tensor, bias: torch.Tensor | None, cin: int):
+    """OIHW f32 weights (+bias) -> (bf16 [cout_pad, kpad], f32 [cout_pad]) on the host.
+    k = (kh*ks + kw)*cin + c ; cin >= w.shape[1] pads extra input channels with zeros."""
+    w = w_oihw.detach().float().cpu()
+    cout, cin_w, k, _ = w.shape
+    kpad, cout_pad = roundup(k * k * cin, 32), roundup(cout, 128)
+    packed = torch.zeros((cout_pad, k * k, cin), dtype=torch.float32)
+    packed[:cout, :, :cin_w] = w.permute(0, 2, 3, 1).reshape(cout, k * k, cin_w)
+    packed = torch.nn.functional.pad(packed.reshape(cout_pad, k * k * cin), (0, kpad - k * k * cin))
+    b = torch.zeros(cout_pad, dtype=torch.float32)
+    if bias is not None:
+        b[:cout] = bias.detach().float().cpu()
+    return packed.to(torch.bfloat16).contiguous(), b, kpad, cout_pad
+
+
+def pack_input(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """f32 NCHW -> bf16 NHWC (channels zero-padded to out.shape[-1])."""
+    _need_cuda(x, out)
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise RuntimeError("pack_input: x must be contiguous float32 NCHW")
+    n, c, h, w = x.shape
+    if out.dtype != torch.bfloat16 or tuple(out.shape[:3]) != (n, h, w) or not out.is_contiguous():
+        raise RuntimeError("pack_input: out must be contiguous bf16 [n,h,w,c_pad]")
+    check(load().yolo_pack_input_nchw_f32(_ptr(x), _ptr(out), n, c, h, w, out.shape[3], stream_ptr()), "pack_input")
+    return out
+
+
+def conv_desc(*, n, h, w, cin, in_c_total, in_c_offset, cout, out_c_total, out_c_offset, ksize, stride,
+              act, kpad, cout_pad, upsample2x=0, out_dtype=DT_BF16, res=(0, 0), aux=(0, 0)) -> YoloConvDesc:
+    pad = (ksize - 1) // 2
+    d = YoloConvDesc()
+    d.n, d.h, d.w, d.cin, d.in_c_total, d.in_c_offset = n, h, w, cin, in_c_total, in_c_offset
+    d.ho, d.wo = (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
+    d.cout, d.out_c_total, d.out_c_offset = cout, out_c_total, out_c_offset
+    d.ksize, d.stride, d.pad, d.act, d.upsample2x, d.out_dtype = ksize, stride, pad, act, upsample2x, out_dtype
+    d.kpad, d.cout_pad = kpad, cout_pad
+    d.res_c_total, d.res_c_offset = res
+    d.aux_c_total, d.aux_c_offset = aux
+    return d
+
+
+def conv2d(x, w_packed, bias, y, desc: YoloConvDesc, residual=None, y_preadd=None):
+    _need_cuda(x, w_packed, bias, y, residual, y_preadd)
+    check(load().yolo_conv2d_fwd(_ptr(x), _ptr(w_packed), _ptr(bias), _ptr(residual), _ptr(y), _ptr(y_preadd),
+                                 C.byref(desc), stream_ptr()), "conv2d")
+    return y
+
+
+def maxpool(x, y, *, n, h, w, c, in_view, out_view, ksize, stride, pad, dilation=1):
+    _need_cuda(x, y)
+    ho = (h + 2 * pad - dilation * (ksize - 1) - 1) // stride + 1
+    wo = (w + 2 * pad - dilation * (ksize - 1) - 1) // stride + 1
+    check(load().yolo_maxpool_fwd(_ptr(x), _ptr(y), n, h, w, c, in_view[0], in_view[1], ho, wo, out_view[0],
+                                  out_view[1], ksize, stride, pad, dilation, stream_ptr()), "maxpool")
+    return y
+
+
+def spp(buf, *, n, h, w, c):
+    _need_cuda(buf)
+    check(load().yolo_spp_fwd(_ptr(buf), n, h, w, c, stream_ptr()), "spp")
+    return buf
+
+
+def dwconv3x3(x, w9c, bias, y, *, n, h, w, c, in_view, out_view, stride, act):
+    _need_cuda(x, w9c, bias, y)
+    ho, wo = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
+    check(load().yolo_dwconv3x3_fwd(_ptr(x), _ptr(w9c), _ptr(bias), _ptr(y), n, h, w, c, in_view[0], in_view[1],
+                                    ho, wo, out_view[0], out_view[1], stride, act, stream_ptr()), "dwconv3x3")
+    return y
+
+
+def decode(head, anchors_px, nc, stride_px, io, io_row_offset, p=None):
+    """head f32 [bs,ny,nx,ct] -> rows of io f32 [bs,rows_total,5+nc] (+ p f32 [bs,na,ny,nx,5+nc])."""
+    _need_cuda(head, io, p)
+    bs, ny, nx, ct = head.shape
+    na = len(anchors_px)
+    if head.dtype != torch.float32 or io.dtype != torch.float32 or not head.is_contiguous() or not io.is_contiguous():
+        raise RuntimeError("decode: head and io must be contiguous float32")
+    if io.shape[0] != bs or io.shape[2] != nc + 5:
+        raise RuntimeError("decode: io shape mismatch")
+    if p is not None and (tuple(p.shape) != (bs, na, ny, nx, nc + 5) or p.dtype != torch.float32 or not p.is_contiguous()):
+        raise RuntimeError("decode: p shape mismatch")
+    flat = (C.c_float * (2 * na))(*[float(v) for a in anchors_px for v in a])
+    check(load().yolo_decode_fwd(_ptr(head), ct, flat, na, nc, bs, ny, nx, float(stride_px), _ptr(io), io.shape[1],
+                                 io_row_offset, _ptr(p), stream_ptr()), "decode")
+    return io
+
+
+def nms_workspace_bytes(bs, rows, nc) -> int:
+    return int(load().yolo_nms_workspace_bytes(bs, rows, nc))
+
+
+def nms_merge(pred, conf_thres, nms_thres, out_dets, out_idx, out_count, workspace, *, min_wh=2.0,
+              max_per_class=100, mutate_conf=False):
+    _need_cuda(pred, out_dets, out_idx, out_count, workspace)
+    if pred.dtype != torch.float32 or pred.dim() != 3 or not pred.is_contiguous():
+        raise RuntimeError("nms: prediction must be contiguous float32 [bs, rows, 5+nc]")
+    bs, rows, no = pred.shape
+    cap = out_dets.shape[1]
+    if tuple(out_dets.shape) != (bs, cap, 7) or tuple(out_idx.shape) != (bs, cap) or out_count.numel() != bs:
+        raise RuntimeError("nms: output shape mismatch")
+    if out_dets.dtype != torch.float32 or out_idx.dtype != torch.int32 or out_count.dtype != torch.int32:
+        raise RuntimeError("nms: output dtype mismatch")
+    check(load().yolo_nms_merge(_ptr(pred), bs, rows, no - 5, float(conf_thres), float(nms_thres), float(min_wh),
+                                int(max_per_class), int(bool(mutate_conf)), _ptr(out_dets), _ptr(out_idx),
+                                _ptr(out_count), cap, _ptr(workspace), workspace.numel() * workspace.element_size(),
+                                stream_ptr()), "nms_merge")
+
+
+def run_ops(op_array, n_ops: int):
+    check(load().yolo_run_ops(op_array, n_ops, stream_ptr()), "run_ops")

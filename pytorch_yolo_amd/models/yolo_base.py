@@ -1,0 +1,186 @@
+"""Host mirror of reference models/yolo_base.py for the HIP path.
+
+The classes keep the reference's constructor arguments, attribute names and
+``state_dict`` layout (``<block>.sequence.conv.weight``,
+``<block>.sequence.batch_norm.*``; after ``fuse()``: ``<block>.sequence.0.*``)
+so checkpoints move between the two unchanged.  The ``nn.Conv2d`` /
+``nn.BatchNorm2d`` members are parameter containers only: the arithmetic runs
+in libyolo_hip.so.  There is no eager / CPU path.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import engine
+from ..utils.torch_utils import fold_conv_bn, fuse_conv_and_bn
+from .yolo_layer import YOLOLayer
+
+DEFAULT_ANCHORS = (((10.0, 14.0), (23.0, 27.0), (37.0, 58.0)),
+                   ((81.0, 82.0), (135.0, 169.0), (344.0, 319.0)))   # reference yolo_base.py:88-89
+
+
+class ConvBlock(nn.Module):
+    """conv(no bias) + BatchNorm + LeakyReLU(0.1) — reference yolo_base.py:19-44."""
+
+    def __init__(self, in_channels, out_channels, size=3, stride=1, pad=True):
+        super().__init__()
+        if not pad:
+            raise NotImplementedError("pad=False ConvBlocks are not used by the hot-path models")
+        if size not in (1, 3) or stride not in (1, 2):
+            raise NotImplementedError("HIP conv supports 1x1/3x3, stride 1/2")
+        self.sequence = nn.Sequential(OrderedDict([
+            ("conv", nn.Conv2d(in_channels, out_channels, size, stride, (size - 1) // 2, bias=False)),
+            ("batch_norm", nn.BatchNorm2d(out_channels)),
+            ("activation", nn.LeakyReLU(0.1, inplace=True)),
+        ]))
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.size, self.stride = size, stride
+
+    @property
+    def is_fused(self) -> bool:
+        return not hasattr(self.sequence, "batch_norm")
+
+    def folded(self):
+        """(weight OIHW f32, bias f32) with the BN folded in (torch_utils.py:33-60)."""
+        if self.is_fused:
+            conv = self.sequence[0]
+            return conv.weight.detach().float().cpu(), conv.bias.detach().float().cpu()
+        conv, bn = self.sequence.conv, self.sequence.batch_norm
+        return fold_conv_bn(conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+
+    def fuse(self):
+        """Reference ConvBlock.fuse (yolo_base.py:46-57): sequence becomes [Conv2d(bias), LeakyReLU, ...]."""
+        if self.is_fused:
+            return
+        rest = [m for name, m in self.sequence.named_children() if name not in ("conv", "batch_norm")]
+        self.sequence = nn.Sequential(fuse_conv_and_bn(self.sequence.conv, self.sequence.batch_norm), *rest)
+
+    def _trace(self, g: engine.Recorder, x, **kw):
+        return g.conv(x, self.folded(), stride=self.stride, act="leaky", **kw)
+
+    def forward(self, x):
+        return engine.run_standalone(lambda g, s: self._trace(g, s), x)
+
+
+class MaxPool(nn.Module):
+    """Reference MaxPool (yolo_base.py:60-66): pad (size-1)//2, except (2,1) = pad 1 / dilation 2."""
+
+    def __init__(self, size, stride):
+        super().__init__()
+        self.size, self.stride = size, stride
+
+    def _trace(self, g, x):
+        return g.maxpool(x, self.size, self.stride)
+
+    def forward(self, x):
+        return engine.run_standalone(lambda g, s: self._trace(g, s), x)
+
+
+class ConvPoolBlock(ConvBlock):
+    """ConvBlock followed by a MaxPool — reference yolo_base.py:69-80."""
+
+    def __init__(self, in_channels, out_channels, conv_size=3, conv_stride=1, conv_pad=True,
+                 pool_size=2, pool_stride=2):
+        super().__init__(in_channels, out_channels, conv_size, conv_stride, conv_pad)
+        self.sequence.add_module("max_pool", MaxPool(pool_size, pool_stride))
+
+    @property
+    def pool(self) -> MaxPool:
+        return self.sequence[-1]
+
+    def _trace(self, g, x, **kw):
+        return self.pool._trace(g, super()._trace(g, x, **kw))
+
+
+class YOLOBase(nn.Module):
+    """Constructor contract of reference YOLOBase (yolo_base.py:84-110)."""
+
+    def __init__(self, in_channels=3, n_class=80, kernels_divider=1, anchors=DEFAULT_ANCHORS,
+                 onnx=False, in_shape=None, hyper_params=None):
+        super().__init__()
+        if onnx:
+            raise NotImplementedError("onnx=True selects the export branch, which is out of scope (SURVEY §2 #13)")
+        self.header_info = np.zeros(5, dtype=np.int32)
+        self.seen = self.header_info[3]
+        self.hyper_params = hyper_params
+        self.n_class = n_class
+        self.onnx = False
+        self.in_channels = in_channels
+        self.anchors = anchors
+        self.kernels_divider = kernels_divider
+        self.in_shape = in_shape
+        self.yolo_layer_input_size = 15 + 3 * n_class           # yolo_base.py:105
+        self.encoder = None
+        self._plans = {}
+        self.use_hip_graph = False
+
+    def _create_yolo_layers(self, device="cpu"):
+        """One YOLOLayer per anchor group, in order (yolo_base.py:117-136)."""
+        return [YOLOLayer(a, self.n_class, self.anchors, False) for a in self.anchors]
+
+    # ---- cache control: any change of parameters invalidates the packed weights -------------------
+    def invalidate(self):
+        self._plans = {}
+
+    def _apply(self, fn, *a, **kw):
+        self.invalidate()
+        return super()._apply(fn, *a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        self.invalidate()
+        return super().load_state_dict(*a, **kw)
+
+    def fuse(self):
+        """Reference YOLOBase.fuse (yolo_base.py:112-115)."""
+        for m in self.modules():
+            if isinstance(m, ConvBlock):
+                m.fuse()
+        self.invalidate()
+
+    # ---- the path -----------------------------------------------------------------------------------
+    def _trace(self, g: engine.Recorder, x):
+        raise NotImplementedError
+
+    def plan_for(self, x: torch.Tensor) -> engine.Plan:
+        if x.dim() != 4 or x.shape[1] != self.in_channels:
+            raise RuntimeError(f"expected input [bs,{self.in_channels},H,W], got {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise RuntimeError("pytorch_yolo_amd runs on a ROCm device only: move the input to cuda "
+                               "(there is no CPU fallback)")
+        key = (tuple(x.shape), x.device)
+        plan = self._plans.get(key)
+        if plan is None:
+            bs, c, h, w = x.shape
+            rec = engine.Recorder(bs, c, h, w)
+            self._trace(rec, rec.input)
+            plan = engine.Plan(rec, x.device, self.n_class, max(h, w))    # img_size, yolov3_spp.py:142
+            self._plans[key] = plan
+        return plan
+
+    def forward(self, x):
+        """eval: (io [bs, sum(3*ny*nx), 5+nc], (p_k [bs,3,ny,nx,5+nc], ...)) like the reference
+        (yolov3_spp.py:141-164, yolov3_tiny.py:79-100)."""
+        if self.training:
+            raise NotImplementedError(
+                "training-mode forward (batch-statistics BN, raw p list) is outside the inference hot path; "
+                "call .eval() first")
+        if x.dtype != torch.float32:
+            x = x.float()
+        x = x.contiguous()
+        plan = self.plan_for(x)
+        for hd in plan.heads:
+            hd["layer"]._sync_grid_attrs(hd["sym"].h, hd["sym"].w, plan.img_size, x.device)
+        if self.use_hip_graph:
+            return plan.run_graph(x)
+        return plan.run(x)
+
+    def detect(self, x, conf_thres=0.5, nms_thres=0.5):
+        """The composition inside reference test_model (utils/utils.py:374-378):
+        ``non_max_suppression(model(x)[0], conf_thres, nms_thres)``."""
+        from ..utils.utils import non_max_suppression
+        io, _ = self.forward(x)
+        return non_max_suppression(io, conf_thres, nms_thres)

@@ -1,0 +1,93 @@
+"""Host mirror of the post-process part of reference utils/utils.py.
+
+``non_max_suppression`` keeps the reference signature and return value
+(utils.py:200-206,293) and runs the batched MERGE-NMS kernels (csrc/nms.hip).
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import kernels as K
+
+MIN_WH = 2.0               # reference utils.py:207
+MAX_PER_CLASS = 100        # reference utils.py:247-250
+
+_ws_cache = {}
+
+
+def _workspace(device, bs, rows, nc):
+    key = (device, bs, rows, nc)
+    ws = _ws_cache.get(key)
+    if ws is None:
+        ws = torch.empty(K.nms_workspace_bytes(bs, rows, nc), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def nms_capacity(rows: int, nc: int) -> int:
+    """Upper bound on kept rows per image: every class keeps at most MAX_PER_CLASS."""
+    return max(1, min(rows, nc * MAX_PER_CLASS))
+
+
+def nms_raw(prediction: torch.Tensor, conf_thres: float, nms_thres: float, inplace_conf: bool = False,
+            out=None):
+    """Launch only (no host sync).  Returns (dets [bs,cap,7], idx [bs,cap], count [bs]) device tensors;
+    rows beyond count[b] are unspecified.  ``out`` lets a caller pass static buffers (graph capture)."""
+    if prediction.dim() != 3:
+        raise RuntimeError("prediction must be [bs, rows, 5+nc]")
+    if not prediction.is_cuda:
+        raise RuntimeError("pytorch_yolo_amd.non_max_suppression runs on a ROCm device only (no CPU fallback)")
+    if prediction.dtype != torch.float32 or not prediction.is_contiguous():
+        if inplace_conf:
+            raise RuntimeError("inplace_conf needs a contiguous float32 prediction tensor")
+        prediction = prediction.float().contiguous()
+    bs, rows, no = prediction.shape
+    nc = no - 5
+    if out is None:
+        cap = nms_capacity(rows, nc)
+        dev = prediction.device
+        out = (torch.empty((bs, cap, 7), dtype=torch.float32, device=dev),
+               torch.empty((bs, cap), dtype=torch.int32, device=dev),
+               torch.empty((bs,), dtype=torch.int32, device=dev))
+    K.nms_merge(prediction, conf_thres, nms_thres, out[0], out[1], out[2], _workspace(prediction.device, bs, rows, nc),
+                min_wh=MIN_WH, max_per_class=MAX_PER_CLASS, mutate_conf=inplace_conf)
+    return out
+
+
+def split_detections(dets, idx, count, with_indices=False):
+    """Device buffers -> the reference's ``list[Tensor[n,7] | None]`` (one D2H copy of the counts)."""
+    counts = count.cpu().tolist()
+    cap = dets.shape[1]
+    out, out_idx = [], []
+    for b, n in enumerate(counts):
+        if n > cap:
+            raise RuntimeError(f"image {b}: {n} detections exceed the output capacity {cap}")
+        out.append(dets[b, :n].clone() if n else None)
+        out_idx.append(idx[b, :n].clone().long() if n else None)
+    return (out, out_idx) if with_indices else out
+
+
+def non_max_suppression(prediction, conf_thres=0.5, nms_thres=0.5, inplace_conf=False, with_indices=False):
+    """Drop-in for reference ``non_max_suppression`` (utils.py:200-293, 'MERGE' style).
+
+    Returns a list (len bs) of ``Tensor[n,7]`` = (x1, y1, x2, y2, conf, class_conf, class) sorted by
+    conf descending, or ``None`` for an image with no detections.
+
+    Differences, both opt-in to the reference behaviour:
+      * the reference overwrites ``prediction[..., 4]`` with obj*class_conf (:213); here the input
+        is left untouched unless ``inplace_conf=True``;
+      * ``with_indices=True`` additionally returns, per image, the input row of each kept box.
+    The reference's unstable argsort (:237,:291) is replaced by a total order
+    (conf desc, then class, then input row) — identical whenever conf values are distinct.
+    """
+    return split_detections(*nms_raw(prediction, conf_thres, nms_thres, inplace_conf), with_indices=with_indices)
+
+
+def xywh2xyxy(x):
+    """Reference utils.py:46-60 (kept for API compatibility; the NMS kernel does this itself)."""
+    y = torch.zeros_like(x)
+    y[:, 0] = x[:, 0] - x[:, 2] / 2
+    y[:, 1] = x[:, 1] - x[:, 3] / 2
+    y[:, 2] = x[:, 0] + x[:, 2] / 2
+    y[:, 3] = x[:, 1] + x[:, 3] / 2
+    return y

@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference, read-only).  The
+reference package cannot be imported as a whole (its __init__ pulls torchvision
+and a broken openvino converter), so a bare parent package is
+registered and only the hot-path modules are imported:
+    pytorch_yolo.models.{yolov3_tiny,yolov3_spp}   pytorch_yolo.utils.utils
+``pycocotools`` (used by the eval harness only) is stubbed.
+
+Inputs and weights come from seeded generators (tests/_cases.py,
+pytorch_yolo_amd/utils/synthetic.py); the fixtures hold reference OUTPUTS only:
+
+  kat.npz                       SURVEY.md §4 known answers re-captured here
+  model_<case>.npz              io, p_k of small models (full tensors) + fused-forward io
+  full_<case>.npz               sampled io rows, per-column float64 sums, NMS dets + kept idx
+  nms_<case>.npz                dets / kept idx / mutated column 4 per image
+  state_keys.json               state_dict key -> shape of the reference models (plain and fused)
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+warnings.filterwarnings("ignore")
+
+REF = "/root/reference/pytorch_yolo"
+
+
+def import_reference():
+    pkg = types.ModuleType("pytorch_yolo")
+    pkg.__path__ = [REF]
+    sys.modules["pytorch_yolo"] = pkg
+    for name in ("pycocotools", "pycocotools.cocoeval"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["pycocotools.cocoeval"].COCOeval = object
+    from pytorch_yolo.models.yolov3_spp import YOLOv3SPP, DownSample
+    from pytorch_yolo.models.yolov3_tiny import YOLOv3Tiny
+    from pytorch_yolo.models.yolo_base import MaxPool
+    from pytorch_yolo.utils.utils import non_max_suppression
+    return dict(spp=YOLOv3SPP, tiny=YOLOv3Tiny, MaxPool=MaxPool, DownSample=DownSample,
+                nms=non_max_suppression)
+
+
+def kept_indices(pred_before, dets):
+    """Recover, for each output row of the reference NMS, the input row that was
+    the pivot of its merge group: conf (col 4) and class are copied unchanged from
+    the pivot (utils.py:274), and conf values are unique in the golden inputs."""
+    cls = pred_before[:, 5:]
+    cpred = np.argmax(cls, 1)
+    conf = pred_before[:, 4] * cls[np.arange(len(cls)), cpred]
+    out = []
+    for row in dets:
+        hit = np.nonzero((conf == row[4]) & (cpred == int(row[6])))[0]
+        assert hit.size == 1, "golden input has a conf tie — pick another seed"
+        out.append(hit[0])
+    return np.asarray(out, dtype=np.int64)
+
+
+def run_ref_nms(ref, pred_np, conf, iou):
+    pred = torch.from_numpy(pred_np.copy())
+    dets = ref["nms"](pred, conf, iou)
+    out = {}
+    for b, d in enumerate(dets):
+        out[f"col4_{b}"] = pred[b, :, 4].numpy().copy()      # reference mutates it (utils.py:213)
+        if d is None:
+            out[f"count_{b}"] = np.int64(0)
+            continue
+        d = d.numpy()
+        out[f"count_{b}"] = np.int64(len(d))
+        out[f"dets_{b}"] = d
+        out[f"kept_{b}"] = kept_indices(pred_np[b], d)
+    return out
+
+
+def main():
+    import _cases as C
+    from pytorch_yolo_amd.utils.synthetic import synth_images, synth_state_dict
+
+    torch.set_num_threads(8)
+    ref = import_reference()
+
+    def save(name, **arrs):
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **arrs)
+        print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+    # ---- known answers -------------------------------------------------
+    mp = ref["MaxPool"](2, 1)(torch.arange(16.).view(1, 1, 4, 4)).numpy()
+    pred = torch.from_numpy(C.NMS_KAT_ROWS.copy())[None]
+    kat = ref["nms"](pred, **C.NMS_KAT_ARGS)[0].numpy()
+    ds = ref["DownSample"](4, 8, repeat=1).eval()
+    ds.load_state_dict(synth_state_dict(ds.state_dict(), 5))
+    xin = synth_images(1, 16, 16, 6, channels=4)
+    with torch.no_grad():
+        ds_x, ds_sub = ds(xin)
+    save("kat", maxpool21=mp, nms_kat=kat, nms_kat_col4=pred[0, :, 4].numpy(),
+         downsample_x=ds_x.numpy(), downsample_sub=ds_sub.numpy())
+
+    # ---- state_dict key layout (un-fused and fused) the product must reproduce ------------
+    import json
+    keys = {}
+    for fam, kw in (("tiny", dict(kernels_divider=2)), ("spp", dict(kernels_divider=4, anchors=C.SPP_ANCHORS))):
+        m = ref[fam](**kw)
+        keys[fam] = {k: list(v.shape) for k, v in m.state_dict().items()}
+        m.fuse()
+        keys[fam + "_fused"] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    with open(os.path.join(HERE, "state_keys.json"), "w") as f:
+        json.dump(keys, f, indent=0)
+
+    # ---- small models, full tensors ----------------------------------------------------
+    for name, (family, kw, bs, h, w, wseed, xseed) in C.MODEL_CASES.items():
+        model = ref[family](**kw).eval()
+        model.load_state_dict(synth_state_dict(model.state_dict(), wseed, n_class=kw["n_class"]))
+        x = synth_images(bs, h, w, xseed)
+        with torch.no_grad():
+            io, p = model(x)
+            model.fuse()
+            io_fused, _ = model(x)
+        arrs = {"io": io.numpy(), "io_fused": io_fused.numpy()}
+        arrs.update({f"p{k}": t.numpy() for k, t in enumerate(p)})
+        save("model_" + name, **arrs)
+
+    # ---- BASELINE.json configs at full size: samples + checksums + NMS ------------------
+    for name, (family, kw, bs, h, w, wseed, xseed) in C.FULL_CASES.items():
+        model = ref[family](**kw).eval()
+        model.load_state_dict(synth_state_dict(model.state_dict(), wseed, n_class=kw["n_class"]))
+        x = synth_images(bs, h, w, xseed)
+        with torch.no_grad():
+            io, p = model(x)
+        io_np = io.numpy()
+        rows = C.sample_rows(io_np.shape[1])
+        arrs = {"rows": rows, "io_rows": io_np[:, rows], "io_colsum": io_np.astype(np.float64).sum(1),
+                "io_shape": np.asarray(io_np.shape)}
+        for k, t in enumerate(p):
+            arrs[f"p{k}_sum"] = np.float64(t.double().sum().item())
+            arrs[f"p{k}_shape"] = np.asarray(t.shape)
+        arrs.update({"nms_" + k: v for k, v in run_ref_nms(ref, io_np, C.NMS_FULL["conf_thres"], C.NMS_FULL["nms_thres"]).items()
+                     if not k.startswith("col4")})
+        save("full_" + name, **arrs)
+
+    # ---- NMS on synthetic predictions ---------------------------------------------------
+    for name in C.NMS_CASES:
+        pred_np, conf, iou = C.nms_case_inputs(name)
+        save(name, **run_ref_nms(ref, pred_np, conf, iou))
+
+
+if __name__ == "__main__":
+    main()

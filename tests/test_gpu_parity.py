@@ -1,0 +1,336 @@
+"""GPU parity tests: every call goes through the C-ABI of libyolo_hip.so and is compared with the
+CPU oracle (oracle/) on the same seeded inputs, and with the reference's golden vectors.
+
+Tolerances (stated once, used below):
+  * pools / SPP / pack: exact (max and rounding are order-free).
+  * conv (bf16 in, fp32 accumulate): against an fp32 conv of the SAME bf16-rounded operands,
+    |err| <= 2e-3 * sqrt(K)-scaled bound -> we use rtol 1e-2 on the bf16-rounded output (1 bf16 ulp = 2^-8).
+  * decode: fp32, rtol 2e-6 / atol 1e-5 vs torch (expf vs Sleef exp differ by <= 1 ulp).
+  * NMS: kept-index sets, conf, class_conf, class BIT-EXACT vs the oracle; merged boxes bit-exact vs the
+    oracle (same sequential fp32 order) and within 2e-4 px of the reference golden.
+  * whole model in bf16 vs the fp32 oracle: boxes within max(1.5 px, 2 %), scores within 2e-2
+    (bf16 activations through up to 75 conv layers); measured values are printed.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import _cases as C
+from helpers import build_case, load_golden, oracle_forward
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _bf16r(t):
+    return t.to(torch.bfloat16).float()
+
+
+def _nhwc(t):      # NCHW f32 -> NHWC bf16 on device
+    return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+
+
+def _nchw(t):      # NHWC (any dtype) on device -> NCHW f32 on host
+    return t.float().permute(0, 3, 1, 2).contiguous().cpu()
+
+
+# ------------------------------------------------------------------------------------------------
+def test_library_loaded():
+    from pytorch_yolo_amd import _lib
+    assert _lib.load().yolo_abi_version() == 1
+
+
+def test_pack_input_exact():
+    from pytorch_yolo_amd import kernels as K
+    x = torch.rand(3, 3, 17, 23)
+    out = torch.full((3, 17, 23, 8), 7.0, dtype=torch.bfloat16, device=DEV)
+    K.pack_input(x.to(DEV), out)
+    got = _nchw(out)
+    assert torch.equal(got[:, :3], _bf16r(x)) and torch.count_nonzero(got[:, 3:]) == 0
+
+
+CONV_CASES = [
+    # n, h, w, cin, cout, k, stride, act, residual, aux, upsample, f32
+    (2, 16, 16, 8, 32, 3, 1, "leaky", False, False, False, False),     # first-layer shape: K=72 -> taps straddle K steps
+    (2, 20, 20, 64, 128, 3, 1, "leaky", True, True, False, False),     # residual + pre-add copy
+    (1, 33, 29, 32, 64, 3, 2, "leaky", False, False, False, False),    # odd size, stride 2
+    (3, 13, 13, 256, 255, 1, 1, "none", False, False, False, True),    # detection head: 255 couts, fp32 store
+    (2, 10, 10, 128, 64, 1, 1, "leaky", False, False, True, False),    # 2x nearest upsample on store
+    (1, 40, 40, 16, 16, 3, 1, "relu6", False, False, False, False),    # cin not a multiple of 32
+    (2, 7, 9, 96, 24, 1, 1, "none", True, False, False, False),        # linear bottleneck + residual
+    (1, 26, 26, 384, 256, 3, 1, "leaky", False, False, False, False),  # tiny-yolo concat conv
+    (1, 9, 9, 1024, 512, 1, 1, "leaky", False, False, False, False),   # long K
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "n%d_%dx%d_c%d-%d_k%d_s%d_%s_r%d_a%d_u%d_f%d" % tuple(int(v) if not isinstance(v, str) else v for v in c))
+def test_conv_kernel(case):
+    from pytorch_yolo_amd import kernels as K
+    n, h, w, cin, cout, k, stride, act, use_res, use_aux, up, f32 = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    pad = (k - 1) // 2
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    res = torch.randn(n, cout, ho, wo, generator=g) if use_res else None
+    # views with channel offsets on every tensor to exercise the concat plumbing
+    in_ct, in_co = cin + 16, 8
+    xin = torch.zeros(n, h, w, in_ct, dtype=torch.bfloat16, device=DEV)
+    xin[..., in_co:in_co + cin] = _nhwc(x)
+    oh, ow = (2 * ho, 2 * wo) if up else (ho, wo)
+    out_ct = (K.roundup(cout, 8) + 8)
+    out_co = 8
+    y = torch.full((n, oh, ow, out_ct), -77.0, dtype=torch.float32 if f32 else torch.bfloat16, device=DEV)
+    aux = torch.full((n, ho, wo, cout + 8), -77.0, dtype=torch.bfloat16, device=DEV) if use_aux else None
+    rin = _nhwc(res) if use_res else None
+    wp, bp, kpad, cout_pad = K.pack_conv_weight(wt, bias, cin)
+    from pytorch_yolo_amd._lib import ACT_LEAKY01, ACT_NONE, ACT_RELU6, DT_BF16, DT_F32
+    d = K.conv_desc(n=n, h=h, w=w, cin=cin, in_c_total=in_ct, in_c_offset=in_co, cout=cout, out_c_total=out_ct,
+                    out_c_offset=out_co, ksize=k, stride=stride,
+                    act={"leaky": ACT_LEAKY01, "none": ACT_NONE, "relu6": ACT_RELU6}[act], kpad=kpad, cout_pad=cout_pad,
+                    upsample2x=int(up), out_dtype=DT_F32 if f32 else DT_BF16,
+                    res=(cout, 0) if use_res else (0, 0), aux=(cout + 8, 8) if use_aux else (0, 0))
+    K.conv2d(xin, wp.to(DEV), bp.to(DEV), y, d, residual=rin, y_preadd=aux)
+    torch.cuda.synchronize()
+    # fp32 reference on the same bf16-rounded operands
+    ref = F.conv2d(_bf16r(x), _bf16r(wt), bias, stride=stride, padding=pad)
+    ref = {"leaky": lambda t: F.leaky_relu(t, 0.1), "none": lambda t: t, "relu6": F.relu6}[act](ref)
+    pre = ref
+    if use_res:
+        ref = ref + _bf16r(res)
+    if up:
+        ref = F.interpolate(ref, scale_factor=2, mode="nearest")
+    got = _nchw(y[..., out_co:out_co + cout])
+    tol = dict(rtol=1e-5, atol=2e-4) if f32 else dict(rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(got, ref, **tol)
+    # nothing outside the view is touched
+    assert torch.all(y[..., :out_co] == -77.0) and torch.all(y[..., out_co + cout:] == -77.0)
+    if use_aux:
+        torch.testing.assert_close(_nchw(aux[..., 8:]), pre, rtol=1e-2, atol=1e-2)
+        assert torch.all(aux[..., :8] == -77.0)
+
+
+@pytest.mark.parametrize("k,s", [(2, 2), (2, 1), (5, 1), (9, 1), (13, 1), (3, 2)])
+def test_maxpool_exact(k, s):
+    from pytorch_yolo_amd.models.yolo_base import MaxPool
+    from oracle.blocks import max_pool
+    x = _bf16r(torch.randn(2, 16, 13, 20))
+    got = MaxPool(k, s)(x.to(DEV)).cpu()
+    assert torch.equal(got, max_pool(x, k, s))
+
+
+def test_maxpool21_kat():
+    from pytorch_yolo_amd.models.yolo_base import MaxPool
+    x = torch.arange(16.).view(1, 1, 4, 4).repeat(1, 8, 1, 1)
+    got = MaxPool(2, 1)(x.to(DEV)).cpu()
+    assert torch.equal(got[0, 0], torch.tensor([[5., 6, 7, 6], [9, 10, 11, 10], [13, 14, 15, 14], [9, 10, 11, 10]]))
+    assert np.array_equal(got[0, 3].numpy(), load_golden("kat")["maxpool21"][0, 0])
+
+
+@pytest.mark.parametrize("h,w", [(20, 20), (13, 17), (4, 3), (72, 72)])
+def test_spp_exact(h, w):
+    from pytorch_yolo_amd import kernels as K
+    from oracle.blocks import max_pool
+    c = 24
+    x = _bf16r(torch.randn(2, c, h, w))
+    buf = torch.zeros(2, h, w, 4 * c, dtype=torch.bfloat16, device=DEV)
+    buf[..., 3 * c:] = _nhwc(x)
+    K.spp(buf, n=2, h=h, w=w, c=c)
+    got = _nchw(buf)
+    want = torch.cat([max_pool(x, 5, 1), max_pool(x, 9, 1), max_pool(x, 13, 1), x], 1)
+    assert torch.equal(got, want)
+
+
+def test_dwconv():
+    from pytorch_yolo_amd import kernels as K
+    from pytorch_yolo_amd._lib import ACT_RELU6
+    for stride in (1, 2):
+        x = torch.randn(2, 32, 15, 18)
+        wt = torch.randn(32, 1, 3, 3) * 0.3
+        b = torch.randn(32) * 0.1
+        ho, wo = (15 - 1) // stride + 1, (18 - 1) // stride + 1
+        y = torch.zeros(2, ho, wo, 32, dtype=torch.bfloat16, device=DEV)
+        K.dwconv3x3(_nhwc(x), wt.reshape(32, 9).t().contiguous().to(DEV), b.to(DEV), y, n=2, h=15, w=18, c=32,
+                    in_view=(32, 0), out_view=(32, 0), stride=stride, act=ACT_RELU6)
+        ref = F.relu6(F.conv2d(_bf16r(x), wt, b, stride=stride, padding=1, groups=32))
+        torch.testing.assert_close(_nchw(y), ref, rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("nc,ny,nx,img", [(80, 13, 13, 416), (3, 4, 6, 96), (1, 5, 5, 160), (80, 80, 80, 640)])
+def test_decode_vs_oracle(nc, ny, nx, img):
+    from pytorch_yolo_amd.models.yolo_layer import YOLOLayer
+    from oracle.blocks import yolo_decode
+    anchors = C.TINY_ANCHORS[1]
+    p_raw = torch.randn(2, 3 * (5 + nc), ny, nx) * 2.0
+    layer = YOLOLayer(anchors, nc, C.TINY_ANCHORS).eval()
+    io, p = layer(p_raw.to(DEV), img)
+    io_ref, p_ref = yolo_decode(p_raw, anchors, nc, img)
+    assert torch.equal(p.cpu(), p_ref)
+    torch.testing.assert_close(io.cpu(), io_ref, rtol=2e-6, atol=1e-5)
+    assert layer.stride == img / max(nx, ny)
+    if nc == 1:
+        assert torch.all(io[..., 5] == 1)
+
+
+# ------------------------------------------------------------------------------------------------
+def _run_nms(pred_np, conf, iou, inplace=False):
+    from pytorch_yolo_amd.utils.utils import non_max_suppression
+    pred = torch.from_numpy(pred_np.copy()).to(DEV)
+    dets, idx = non_max_suppression(pred, conf, iou, inplace_conf=inplace, with_indices=True)
+    to_np = lambda t: None if t is None else t.cpu().numpy()
+    return [to_np(d) for d in dets], [to_np(i) for i in idx], pred.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", list(C.NMS_CASES))
+def test_nms_vs_oracle_and_golden(name):
+    from oracle import nms as onms
+    pred, conf, iou = C.nms_case_inputs(name)
+    dets, idx, after = _run_nms(pred, conf, iou, inplace=True)
+    work = pred.copy()
+    odets, okept = onms.non_max_suppression(work, conf, iou)
+    g = load_golden(name)
+    for b in range(pred.shape[0]):
+        assert np.array_equal(after[b, :, 4], work[b, :, 4], equal_nan=True)      # in-place conf like utils.py:213
+        if odets[b] is None:
+            assert dets[b] is None
+            continue
+        assert np.array_equal(idx[b], okept[b]), "kept-index set differs from the oracle"
+        assert np.array_equal(dets[b], odets[b]), "detections differ from the oracle (bit-exact expected)"
+        assert np.array_equal(idx[b], g[f"kept_{b}"]) and np.array_equal(dets[b][:, 4:], g[f"dets_{b}"][:, 4:])
+        np.testing.assert_allclose(dets[b][:, :4], g[f"dets_{b}"][:, :4], rtol=2e-6, atol=2e-4)
+
+
+def test_nms_kat_and_non_mutating_default():
+    dets, idx, after = _run_nms(C.NMS_KAT_ROWS[None], **C.NMS_KAT_ARGS)
+    assert np.allclose(dets[0], C.NMS_KAT_EXPECT, atol=1e-4) and idx[0].tolist() == [0, 2]
+    assert np.array_equal(after[0], C.NMS_KAT_ROWS)                                # default leaves the input alone
+    _, _, after = _run_nms(C.NMS_KAT_ROWS[None], inplace=True, **C.NMS_KAT_ARGS)
+    assert np.allclose(after[0, :, 4], C.NMS_KAT_COL4, atol=1e-6)
+
+
+def test_nms_many_survivors_global_sort_path():
+    """> 8192 survivors in one image: the keys are sorted in the global workspace instead of LDS."""
+    from oracle import nms as onms
+    pred = C.synth_predictions(77, 1, 12000, 4)
+    pred[0, :, 4] = np.maximum(pred[0, :, 4], np.float32(0.5))
+    dets, idx, _ = _run_nms(pred, 0.001, 0.5)
+    odets, okept = onms.non_max_suppression(pred.copy(), 0.001, 0.5)
+    assert np.array_equal(idx[0], okept[0]) and np.array_equal(dets[0], odets[0])
+
+
+# ------------------------------------------------------------------------------------------------
+def _model_errors(io, io_ref):
+    io, io_ref = io.double(), io_ref.double()
+    box = (io[..., :4] - io_ref[..., :4]).abs()
+    box_rel = box / io_ref[..., :4].abs().clamp_min(1.0)
+    score = (io[..., 4:] - io_ref[..., 4:]).abs()
+    return box.max().item(), box_rel.max().item(), score.max().item()
+
+
+def _assert_model_close(io, io_ref, tag):
+    box_abs, box_rel, score = _model_errors(io, io_ref)
+    print(f"[{tag}] bf16-vs-fp32: max box abs {box_abs:.4f} px, max box rel {box_rel:.4f}, max score abs {score:.5f}")
+    ok_box = ((io[..., :4] - io_ref[..., :4]).abs() <= torch.maximum(torch.tensor(1.5), 0.02 * io_ref[..., :4].abs())).all()
+    assert ok_box, f"{tag}: boxes outside max(1.5 px, 2 %)"
+    assert score <= 2e-2, f"{tag}: scores differ by {score}"
+
+
+@pytest.mark.parametrize("name", list(C.MODEL_CASES))
+def test_model_small_vs_oracle_and_golden(name):
+    case = C.MODEL_CASES[name]
+    model, sd, x = build_case(case)
+    io_ref, p_ref = oracle_forward(case, sd, x)
+    model = model.to(DEV)
+    with torch.no_grad():
+        io, p = model(x.to(DEV))
+    assert io.shape == io_ref.shape and [t.shape for t in p] == [t.shape for t in p_ref]
+    _assert_model_close(io.cpu(), io_ref, name)
+    g = load_golden("model_" + name)
+    _assert_model_close(io.cpu(), torch.from_numpy(g["io"]), name + "/golden")
+    # fused weights give the same function
+    model.fuse()
+    with torch.no_grad():
+        io_f, _ = model(x.to(DEV))
+    _assert_model_close(io_f.cpu(), torch.from_numpy(g["io_fused"]), name + "/fused")
+
+
+def test_downsample_sub_is_pre_add():
+    from pytorch_yolo_amd.models.yolov3_spp import DownSample
+    from pytorch_yolo_amd.utils.synthetic import synth_images, synth_state_dict
+    ds = DownSample(8, 16, repeat=1).eval()
+    ds.load_state_dict(synth_state_dict(ds.state_dict(), 5))
+    from oracle.models import darknet_stage
+    x = synth_images(1, 16, 16, 6, channels=8)
+    sd = {"s." + k: v for k, v in ds.state_dict().items()}
+    x_ref, sub_ref = darknet_stage(sd, "s", x, 2)
+    x_out, sub = ds(x.to(DEV))
+    torch.testing.assert_close(x_out.cpu(), x_ref, rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(sub.cpu(), sub_ref, rtol=3e-2, atol=3e-2)
+    assert not torch.allclose(x_out, sub)
+
+
+@pytest.mark.parametrize("name", list(C.FULL_CASES))
+def test_model_full_size(name):
+    """BASELINE.json configs at full size: golden samples + checksums + end-to-end detect()."""
+    case = C.FULL_CASES[name]
+    model, sd, x = build_case(case)
+    g = load_golden("full_" + name)
+    model = model.to(DEV)
+    with torch.no_grad():
+        io, p = model(x.to(DEV))
+    assert list(io.shape) == g["io_shape"].tolist()
+    ref_rows = torch.from_numpy(g["io_rows"])
+    _assert_model_close(io.cpu()[:, g["rows"]], ref_rows, name + "/rows")
+    colsum = io.double().sum(1).cpu().numpy()
+    rel = np.abs(colsum - g["io_colsum"]) / np.maximum(np.abs(g["io_colsum"]), 1.0)
+    print(f"[{name}] column checksum: max rel diff {rel.max():.5f}")
+    assert rel.max() < 2e-2
+    for k, t in enumerate(p):
+        assert list(t.shape) == g[f"p{k}_shape"].tolist()
+        psum = t.double().sum().item()
+        assert abs(psum - float(g[f"p{k}_sum"])) <= 2e-2 * abs(float(g[f"p{k}_sum"])) + 1.0
+    # NMS on the HIP forward's own output equals the oracle NMS on the same tensor, bit for bit
+    from oracle import nms as onms
+    from pytorch_yolo_amd.utils.utils import non_max_suppression
+    dets, idx = non_max_suppression(io, with_indices=True, **C.NMS_FULL)
+    odets, okept = onms.non_max_suppression(io.cpu().numpy().copy(), **C.NMS_FULL)
+    for b in range(io.shape[0]):
+        if odets[b] is None:
+            assert dets[b] is None
+            continue
+        assert np.array_equal(idx[b].cpu().numpy(), okept[b]) and np.array_equal(dets[b].cpu().numpy(), odets[b])
+    n_ref = int(g["nms_count_0"])
+    n_got = 0 if dets[0] is None else len(dets[0])
+    print(f"[{name}] detections: HIP bf16 path {n_got}, fp32 reference {n_ref}")
+    # detect() == the two-line composition (utils.py:374-378)
+    with torch.no_grad():
+        d2 = model.detect(x.to(DEV), **C.NMS_FULL)
+    assert (d2[0] is None) == (dets[0] is None) and (d2[0] is None or torch.equal(d2[0], dets[0]))
+
+
+def test_forward_idempotent_and_graph_replay():
+    case = C.MODEL_CASES["tiny_small"]
+    model, sd, x = build_case(case)
+    model = model.to(DEV)
+    with torch.no_grad():
+        io1, p1 = model(x.to(DEV))
+        io2, _ = model(x.to(DEV))
+        model.use_hip_graph = True
+        io3, p3 = model(x.to(DEV))
+        io3 = io3.clone()
+        io4, _ = model(x.to(DEV))
+    assert torch.equal(io1, io2) and torch.equal(io1, io3) and torch.equal(io1, io4)
+    assert all(torch.equal(a, b) for a, b in zip(p1, p3))
+
+
+def test_cpu_input_fails_loudly():
+    case = C.MODEL_CASES["tiny_small"]
+    model, sd, x = build_case(case)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model(x)
+    model.train()
+    with pytest.raises(NotImplementedError):
+        model(x.to(DEV))
