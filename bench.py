@@ -59,6 +59,23 @@ def conv_flops(plan) -> float:
     return total
 
 
+def host_cores() -> int:
+    """Threads the CPU baseline may use: the cgroup CPU quota if there is one, else the affinity
+    mask, capped at 16 (a 1-GPU box's CPU share; more threads than that only thrash)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(workload: str, seconds_budget: float = 25.0):
     """The oracle (CPU restatement of the reference path) timed on this box's host cores."""
     import numpy as np
@@ -70,11 +87,7 @@ def cpu_baseline(workload: str, seconds_budget: float = 25.0):
     else:
         fwd, anchors, hw = om.spp_forward, om.SPP_ANCHORS, 640
         tmpl = YOLOv3SPP(anchors=SPP_ANCHORS).state_dict()
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        pass
+    cores = host_cores()
     torch.set_num_threads(cores)
     sd = synth_state_dict(tmpl, 1234, n_class=80)
     bs = 4

@@ -66,7 +66,7 @@ typedef struct YoloConvDesc {
   int32_t upsample2x;              /* 1: each output pixel is written to a 2x2 block of a
                                       [n,2ho,2wo,out_c_total] tensor                       */
   int32_t out_dtype;               /* YOLO_DT_BF16 | YOLO_DT_F32 (detection heads)         */
-  int32_t kpad;                    /* packed K = roundup(ksize*ksize*cin, 32)              */
+  int32_t kpad;                    /* packed K = roundup(ksize*ksize*cin, 64)              */
   int32_t cout_pad;                /* packed rows = roundup(cout, 128) (zero rows)         */
   int32_t res_c_total, res_c_offset; /* residual view (bf16), same spatial size as output  */
   int32_t aux_c_total, aux_c_offset; /* pre-add copy view (bf16)                           */

@@ -15,8 +15,9 @@
 // is lane-linear (64-byte rows), conflict-free ds_read_b128 comes from an XOR swizzle applied on the
 // per-lane SOURCE address (chunk ^= (row>>2)&3) and again on the read.  Zero padding (image border,
 // K tail, M tail) costs nothing: those lanes get a voffset beyond the descriptor's num_records and the
-// hardware writes zeros.  Double-buffered, one barrier per K step.
+// hardware writes zeros.  NS-stage LDS ring, counted vmcnt, one raw s_barrier per K step.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -34,6 +35,7 @@ struct ConvArgs {
   int n_tiles;  // cout tiles
   int steps;    // kpad / 32
   uint32_t x_bytes, w_bytes;
+  int debug;    // timing ablations only (YOLO_CONV_DEBUG): 1 no pixel DMA, 2 no weight DMA, 4 no MFMA, 8 no epilogue
 };
 
 __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, uint32_t voffset) {
@@ -47,18 +49,47 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return v;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvArgs a) {
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+
+__device__ __forceinline__ void lds_dma16s(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, uint32_t voffset,
+                                           uint32_t soffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16,
+                                           voffset, soffset, 0, 0);
+}
+
+// BM pixels x BN couts block tile, WAVES_M x WAVES_N waves (4 or 8), K step BK (32 or 64), NS-stage LDS ring.
+// Stage s+NS-1 is in flight (LDS-DMA) while stage s is multiplied: the waits are COUNTED
+// (s_waitcnt vmcnt(N), never 0 in steady state) and the barrier is a raw s_barrier, so the DMA
+// stays in flight across it (a __syncthreads() would drain vmcnt to 0).
+// FAST (cin % BK == 0): a K step never straddles a filter tap, so tap / channel offset are wave-uniform
+// scalars, the image-border test is one precomputed bit per tap, and the weight address advances through
+// the instruction's scalar offset: ~3 VALU per LDS-DMA instead of ~15.
+// LDS_EPI (bf16 output, cout % 64 == 0): the finished tile goes registers -> LDS -> global so that every
+// store instruction writes whole 128-byte channel runs (16 B per lane) instead of 8-byte fragments.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int NS, bool FAST, bool LDS_EPI>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel(const ConvArgs a) {
+  constexpr int NW = WAVES_M * WAVES_N;
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  static_assert(BK == 32 || BK == 64, "BK");
+  static_assert(NS >= 2 && NS <= 4, "ring depth");
   constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N;  // per-wave tile (pixels x couts)
   constexpr int NI = TM / 32, MI = TN / 32;
-  constexpr int PIT = BM / 64, WIT = (BN + 63) / 64;   // LDS-DMA instructions per thread per step
-  constexpr int ROWB = 64;                             // bytes per LDS row (32 bf16)
-  static_assert(TM % 32 == 0 && TN % 32 == 0, "tile");
+  constexpr int ROWB = BK * 2;                         // bytes per LDS row
+  constexpr int CPR = BK / 8;                          // 16-byte chunks per row
+  constexpr int RPP = 1024 / ROWB;                     // rows per 1-KiB LDS-DMA piece (16 or 8)
+  constexpr int BNL = BN < NW * RPP ? NW * RPP : BN;   // weight rows staged (every wave issues the same count)
+  constexpr int PIT = BM / (NW * RPP), WIT = BNL / (NW * RPP);   // LDS-DMA instructions per thread per stage
+  constexpr int LPS = PIT + WIT;
+  constexpr int STAGE_B = (BM + BNL) * ROWB;
+  static_assert(TM % 32 == 0 && TN % 32 == 0 && PIT >= 1 && WIT >= 1, "tile");
+  static_assert(NS * STAGE_B <= 160 * 1024, "LDS");
 
-  __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * ROWB];
-  char* const sW = smem;                     // [2][BN][64B]
-  char* const sX = smem + 2 * BN * ROWB;     // [2][BM][64B]
+  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE_B];   // per stage: [BNL weight rows][BM pixel rows]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -81,56 +112,103 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvArgs a) 
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
 
   // ---- per-thread staging state -----------------------------------------------------------------
-  const int frow = lane >> 2;                          // row inside a 16-row LDS-DMA piece
-  const int chunk = (lane & 3) ^ ((lane >> 4) & 3);    // logical 8-channel chunk this lane fetches
-  int px_base[PIT], px_hi0[PIT], px_wi0[PIT];
-  bool px_ok[PIT];
+  // piece p = it*NW + wave covers LDS rows [p*RPP, (p+1)*RPP); lane -> (row in piece, physical chunk slot).
+  // swizzle: physical slot = logical chunk ^ f(row);  f = (row>>2)&3 for 64-B rows, (row>>1)&7 for 128-B rows.
+  const int frow = lane / CPR;
+  const int fsw = (BK == 32) ? ((lane >> 4) & 3) : (((lane >> 4) + 4 * (wave & 1)) & 7);
+  const int chunk = (lane & (CPR - 1)) ^ fsw;          // logical 8-channel chunk this lane fetches
+  const int ntaps = d.ksize * d.ksize;
+  int px_base[PIT], px_hi0[PIT], px_wi0[PIT];          // generic path
+  uint32_t px_mask[PIT];                               // bit t: tap t of this pixel is inside the image
   const int hw_out = d.ho * d.wo;
 #pragma unroll
   for (int it = 0; it < PIT; ++it) {
-    const int m = m0 + it * 64 + wave * 16 + frow;
-    px_ok[it] = m < a.M;
-    const int mm = px_ok[it] ? m : 0;
+    const int m = m0 + (it * NW + wave) * RPP + frow;
+    const bool ok = m < a.M;
+    const int mm = ok ? m : 0;
     const int b = mm / hw_out, rem = mm - b * hw_out;
     const int oh = rem / d.wo, ow = rem - oh * d.wo;
     px_hi0[it] = oh * d.stride - d.pad;
     px_wi0[it] = ow * d.stride - d.pad;
     px_base[it] = ((b * d.h + px_hi0[it]) * d.w + px_wi0[it]) * d.in_c_total + d.in_c_offset;
+    uint32_t mask = 0;
+    for (int t = 0; t < ntaps; ++t) {
+      const int dh = d.ksize == 3 ? t / 3 : 0, dw = d.ksize == 3 ? t - 3 * dh : 0;
+      const bool in = (unsigned)(px_hi0[it] + dh) < (unsigned)d.h && (unsigned)(px_wi0[it] + dw) < (unsigned)d.w;
+      mask |= (uint32_t)(ok && in) << t;
+    }
+    px_mask[it] = mask;
+    if (FAST) px_base[it] = (px_base[it] + chunk * 8) * 2;   // byte offset of this lane's chunk at tap (0,0)
   }
   uint32_t w_off[WIT];
 #pragma unroll
-  for (int it = 0; it < WIT; ++it)
-    w_off[it] = (uint32_t)(((n0 + it * 64 + wave * 16 + frow) * d.kpad + chunk * 8) * 2);
-  const int ntaps = d.ksize * d.ksize;
-  int tap = (chunk * 8) / d.cin;
-  int kc = chunk * 8 - tap * d.cin;
+  for (int it = 0; it < WIT; ++it) {
+    const int row = (it * NW + wave) * RPP + frow;
+    w_off[it] = row < BN ? (uint32_t)(((n0 + row) * d.kpad + chunk * 8) * 2) : kOobOffset;
+  }
+  // generic: this lane's chunk has its own (tap, channel); FAST: both are wave-uniform scalars
+  int tap = FAST ? 0 : (chunk * 8) / d.cin;
+  int kc = FAST ? 0 : chunk * 8 - tap * d.cin;
 
-  auto stage = [&](int buf, int step) {
-    int dh = 0, dw = 0;
+  // One stage = LPS LDS-DMA instructions per thread (PIT pixel pieces, then WIT weight pieces).
+  // issue(buf, step, lo, hi) launches pieces [lo, hi) so that the main loop can spread them between
+  // its MFMA groups instead of bursting them right after the barrier (an LDS-DMA costs the issuing
+  // wave ~60-180 cycles; bursting 8 of them idles the matrix pipe of every wave at once).
+  int st_dh = 0, st_dw = 0;
+  auto stage_begin = [&]() {
+    st_dh = st_dw = 0;
     if (d.ksize == 3) {
-      dh = (tap * 11) >> 5;  // tap / 3 for tap < 12
-      dw = tap - 3 * dh;
+      st_dh = (tap * 11) >> 5;  // tap / 3 for tap < 12
+      st_dw = tap - 3 * st_dh;
     }
-    const bool tap_ok = tap < ntaps;
-    const int tap_off = (dh * d.w + dw) * d.in_c_total + kc;
-    char* const xb = sX + buf * (BM * ROWB) + wave * 1024;
+  };
+  auto issue = [&](int buf, int step, int lo, int hi) {
+    char* const wb = smem + buf * STAGE_B + wave * 1024;
+    char* const xb = wb + BNL * ROWB;
+    if (FAST) {
+      const uint32_t tap_off = (uint32_t)(((st_dh * d.w + st_dw) * d.in_c_total + kc) * 2);
+      const uint32_t bit = 1u << tap;
 #pragma unroll
-    for (int it = 0; it < PIT; ++it) {
-      const int hi = px_hi0[it] + dh, wi = px_wi0[it] + dw;
-      const bool ok = px_ok[it] && tap_ok && (unsigned)hi < (unsigned)d.h && (unsigned)wi < (unsigned)d.w;
-      const uint32_t voff = ok ? (uint32_t)(px_base[it] + tap_off) * 2u : kOobOffset;
-      lds_dma16(rx, xb + it * 4096, voff);
-    }
-    char* const wb = sW + buf * (BN * ROWB) + wave * 1024;
+      for (int it = 0; it < PIT; ++it) {
+        if (it < lo || it >= hi) continue;
+        const uint32_t voff = (px_mask[it] & bit) ? (uint32_t)px_base[it] + tap_off : kOobOffset;
+        if (!(a.debug & 1)) lds_dma16(rx, xb + it * (NW * 1024), voff);
+      }
 #pragma unroll
-    for (int it = 0; it < WIT; ++it) {
-      if (BN >= 64 || wave * 16 < BN)   // BN == 32: only waves 0,1 carry weight rows
-        lds_dma16(rw, wb + it * 4096, w_off[it] + (uint32_t)step * 64u);
+      for (int it = 0; it < WIT; ++it) {
+        if (PIT + it < lo || PIT + it >= hi) continue;
+        if (!(a.debug & 2)) lds_dma16s(rw, wb + it * (NW * 1024), w_off[it], (uint32_t)step * (BK * 2u));
+      }
+    } else {
+      const bool tap_ok = tap < ntaps;
+      const int tap_off = (st_dh * d.w + st_dw) * d.in_c_total + kc;
+#pragma unroll
+      for (int it = 0; it < PIT; ++it) {
+        if (it < lo || it >= hi) continue;
+        const bool ok = tap_ok && ((px_mask[it] >> (tap_ok ? tap : 0)) & 1u);
+        const uint32_t voff = ok ? (uint32_t)(px_base[it] + tap_off) * 2u : kOobOffset;
+        lds_dma16(rx, xb + it * (NW * 1024), voff);
+      }
+#pragma unroll
+      for (int it = 0; it < WIT; ++it) {
+        if (PIT + it < lo || PIT + it >= hi) continue;
+        const uint32_t voff = w_off[it] == kOobOffset ? kOobOffset : w_off[it] + (uint32_t)step * (BK * 2u);
+        lds_dma16(rw, wb + it * (NW * 1024), voff);
+      }
     }
-    kc += 32;
-    while (kc >= d.cin) {
-      kc -= d.cin;
-      ++tap;
+  };
+  auto stage_end = [&]() {
+    kc += BK;
+    if (FAST) {
+      if (kc >= d.cin) {
+        kc = 0;
+        ++tap;
+      }
+    } else {
+      while (kc >= d.cin) {
+        kc -= d.cin;
+        ++tap;
+      }
     }
   };
 
@@ -143,37 +221,137 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvArgs a) 
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int r32 = lane & 31, khalf = lane >> 5;
+  const int steps = a.steps;
+  constexpr int KS = BK / 16;
 
-  stage(0, 0);
-  for (int s = 0; s < a.steps; ++s) {
-    __syncthreads();  // hipcc drains vmcnt(0) here: step s has landed, step s-1's reads are done
-    if (s + 1 < a.steps) stage((s + 1) & 1, s + 1);
-    const char* wbuf = sW + (s & 1) * (BN * ROWB);
-    const char* xbuf = sX + (s & 1) * (BM * ROWB);
+  // prologue: NS-1 stages in flight
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int g = ks * 2 + khalf;
-      bf16x8 wf[MI], xf[NI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int R = wn * TN + i * 32 + r32;
-        wf[i] = *reinterpret_cast<const bf16x8*>(wbuf + R * ROWB + ((g ^ ((R >> 2) & 3)) << 4));
-      }
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int R = wm * TM + j * 32 + r32;
-        xf[j] = *reinterpret_cast<const bf16x8*>(xbuf + R * ROWB + ((g ^ ((R >> 2) & 3)) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+  for (int p = 0; p < NS - 1; ++p)
+    if (p < steps) {
+      stage_begin();
+      issue(p, p, 0, LPS);
+      stage_end();
     }
+
+  int buf = 0;
+  for (int s = 0; s < steps; ++s) {
+    // stage s must have landed: allow the younger stages (up to NS-2 of them) to stay in flight
+    const int younger = min(NS - 2, steps - 1 - s);
+    if (younger >= 2) wait_vmcnt<2 * LPS>();
+    else if (younger == 1) wait_vmcnt<1 * LPS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();   // everyone's stage s is in LDS; everyone finished reading stage s-1
+    const bool more = s + NS - 1 < steps;
+    int nb = buf + NS - 1;          // ring slot read in iteration s-1: free again after the barrier
+    if (nb >= NS) nb -= NS;
+    if (more) stage_begin();
+    const char* wbuf = smem + buf * STAGE_B;
+    const char* xbuf = wbuf + BNL * ROWB;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (more) issue(nb, s + NS - 1, ks * LPS / KS, (ks + 1) * LPS / KS);
+      if (!(a.debug & 4)) {
+        const int g = ks * 2 + khalf;
+        bf16x8 wf[MI], xf[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int R = wn * TN + i * 32 + r32;
+          const int sw = (BK == 32) ? ((R >> 2) & 3) : ((R >> 1) & 7);
+          wf[i] = *reinterpret_cast<const bf16x8*>(wbuf + R * ROWB + ((g ^ sw) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int R = wm * TM + j * 32 + r32;
+          const int sw = (BK == 32) ? ((R >> 2) & 3) : ((R >> 1) & 7);
+          xf[j] = *reinterpret_cast<const bf16x8*>(xbuf + R * ROWB + ((g ^ sw) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep each DMA slice in front of its MFMA group
+    }
+    if (more) stage_end();
+    if (++buf == NS) buf = 0;
   }
 
+  if (a.debug & 8) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" ::"v"(acc[i][j]));   // keep the accumulators live in the timing-only build path
+#endif
+      }
+    return;
+  }
   // ---- epilogue: lane = pixel (col), registers = couts (row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) ----
   const bool f32_out = d.out_dtype == YOLO_DT_F32;
+  if constexpr (LDS_EPI) {
+    static_assert(TN % 64 == 0, "LDS epilogue works on 64-cout slabs");
+    constexpr int EP = 144;                          // staging row pitch: 64 bf16 + 16 B pad (16-B aligned rows)
+    static_assert(NW * TM * EP <= NS * STAGE_B, "staging fits the ring");
+    __syncthreads();                                 // every wave is done with the last stage: LDS is free
+    char* const stg = smem + wave * (TM * EP);       // private per-wave slab [TM pixels][64 couts]
+#pragma unroll
+    for (int hp = 0; hp < TN / 64; ++hp) {
+      if (n0 + wn * TN + hp * 64 >= d.cout) continue;   // slab beyond cout (cout % 64 == 0: all or nothing)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int row = j * 32 + r32;
+        const int pix = m0 + wm * TM + row;
+        const bool pv = pix < a.M;
+#pragma unroll
+        for (int il = 0; il < 2; ++il) {
+          const int i = hp * 2 + il;
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int cl = il * 32 + g4 * 8 + khalf * 4;            // cout inside the 64-slab
+            const int c0 = n0 + wn * TN + hp * 64 + cl;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + c0);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[i][j][g4 * 4 + e] + bv[e], d.act);
+            if (a.aux && pv) {
+              bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+              *reinterpret_cast<bf16x4*>(a.aux + (long)pix * d.aux_c_total + d.aux_c_offset + c0) = o;
+            }
+            if (a.res && pv) {
+              const bf16x4 rv = *reinterpret_cast<const bf16x4*>(a.res + (long)pix * d.res_c_total + d.res_c_offset + c0);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+            }
+            bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            *reinterpret_cast<bf16x4*>(stg + row * EP + cl * 2) = o;
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();               // LDS ops of one wave execute in order
+      bf16_t* const ybase = reinterpret_cast<bf16_t*>(a.y) + d.out_c_offset + n0 + wn * TN + hp * 64 + (lane & 7) * 8;
+#pragma unroll
+      for (int pass = 0; pass < TM / 8; ++pass) {
+        const int row = pass * 8 + (lane >> 3);
+        const int pix = m0 + wm * TM + row;
+        if (pix < a.M) {
+          const u32x4 val = *reinterpret_cast<const u32x4*>(stg + row * EP + (lane & 7) * 16);
+          if (d.upsample2x) {
+            const int b = pix / hw_out, rem = pix - b * hw_out;
+            const int oh = rem / d.wo, ow = rem - oh * d.wo;
+            const long op = ((long)(b * 2 * d.ho + 2 * oh)) * (2 * d.wo) + 2 * ow;
+#pragma unroll
+            for (int rep = 0; rep < 4; ++rep)
+              *reinterpret_cast<u32x4*>(ybase + (op + (rep >> 1) * 2 * d.wo + (rep & 1)) * d.out_c_total) = val;
+          } else {
+            *reinterpret_cast<u32x4*>(ybase + (long)pix * d.out_c_total) = val;
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int pix = m0 + wm * TM + j * 32 + r32;
@@ -241,24 +419,36 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(const ConvArgs a) 
       }
     }
   }
+  }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int NS, bool FAST, bool LDS_EPI>
 int launch_cfg(const ConvArgs& a, hipStream_t s) {
   const int m_tiles = (a.M + BM - 1) / BM;
   ConvArgs b = a;
   b.n_tiles = (a.d.cout + BN - 1) / BN;
+  b.steps = a.d.kpad / BK;
   const long grid = (long)m_tiles * b.n_tiles;
   if (grid > 0x7fffffffL) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv grid too large");
-  hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N>), dim3((unsigned)grid), dim3(256), 0, s, b);
+  hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, BK, NS, FAST, LDS_EPI>), dim3((unsigned)grid),
+                     dim3(64 * WAVES_M * WAVES_N), 0, s, b);
   return yolo_check_launch("yolo_conv2d_fwd");
 }
+
+int conv_variant_override = -1;
+int conv_debug_flags = 0;   // tuning hook (YOLO_CONV_VARIANT), see yolo_conv2d_launch
 
 }  // namespace
 
 int yolo_conv2d_launch(const void* x, const void* w, const float* bias, const void* res, void* y, void* y_aux,
                        const YoloConvDesc* dp, hipStream_t s) {
   YOLO_REQUIRE(x && w && bias && y && dp, "conv: null pointer");
+  static const bool env_read = [] {
+    if (const char* e = getenv("YOLO_CONV_VARIANT")) conv_variant_override = atoi(e);
+    if (const char* e = getenv("YOLO_CONV_DEBUG")) conv_debug_flags = atoi(e);
+    return true;
+  }();
+  (void)env_read;
   const YoloConvDesc& d = *dp;
   YOLO_REQUIRE(d.ksize == 1 || d.ksize == 3, "conv: ksize %d unsupported (1 or 3)", d.ksize);
   YOLO_REQUIRE(d.stride == 1 || d.stride == 2, "conv: stride %d unsupported", d.stride);
@@ -267,7 +457,7 @@ int yolo_conv2d_launch(const void* x, const void* w, const float* bias, const vo
                "conv: bad input view (cin %d, offset %d, total %d)", d.cin, d.in_c_offset, d.in_c_total);
   YOLO_REQUIRE(d.out_c_offset % 4 == 0 && d.out_c_total % 4 == 0 && d.out_c_offset + d.cout <= d.out_c_total,
                "conv: bad output view (cout %d, offset %d, total %d)", d.cout, d.out_c_offset, d.out_c_total);
-  YOLO_REQUIRE(d.kpad % 32 == 0 && d.kpad >= d.ksize * d.ksize * d.cin, "conv: kpad %d", d.kpad);
+  YOLO_REQUIRE(d.kpad % 64 == 0 && d.kpad >= d.ksize * d.ksize * d.cin, "conv: kpad %d must be a multiple of 64", d.kpad);
   YOLO_REQUIRE(d.cout_pad % 128 == 0 && d.cout_pad >= d.cout, "conv: cout_pad %d", d.cout_pad);
   YOLO_REQUIRE(d.ho == (d.h + 2 * d.pad - d.ksize) / d.stride + 1 && d.wo == (d.w + 2 * d.pad - d.ksize) / d.stride + 1,
                "conv: output size %dx%d inconsistent with input %dx%d k%d s%d p%d", d.ho, d.wo, d.h, d.w, d.ksize,
@@ -290,12 +480,33 @@ int yolo_conv2d_launch(const void* x, const void* w, const float* bias, const vo
   a.d = d;
   a.M = (int)M;
   a.n_tiles = 0;
-  a.steps = d.kpad / 32;
+  a.steps = 0;
   a.x_bytes = (uint32_t)x_bytes;
   a.w_bytes = (uint32_t)w_bytes;
-  if (d.cout <= 32) return launch_cfg<256, 32, 4, 1>(a, s);
-  if (d.cout <= 64) return launch_cfg<256, 64, 4, 1>(a, s);
-  return launch_cfg<128, 128, 2, 2>(a, s);
+  a.debug = conv_debug_flags;
+  const int variant = conv_variant_override >= 0 ? conv_variant_override : 0;
+  const bool fast64 = d.cin % 64 == 0, fast32 = d.cin % 32 == 0;
+  const bool epi = d.out_dtype == YOLO_DT_BF16 && d.cout % 64 == 0 && d.out_c_offset % 8 == 0 && d.out_c_total % 8 == 0 &&
+                   !(conv_debug_flags & 16);
+#define YOLO_CFG(BM, BN, WM, WN, BK, NS, FASTV)                                                           \
+  (epi ? launch_cfg<BM, BN, WM, WN, BK, NS, FASTV, true>(a, s) : launch_cfg<BM, BN, WM, WN, BK, NS, FASTV, false>(a, s))
+  if (d.cout <= 32)
+    return fast32 ? launch_cfg<256, 32, 4, 1, 32, 3, true, false>(a, s) : launch_cfg<256, 32, 4, 1, 32, 3, false, false>(a, s);
+  if (d.cout <= 64) return fast32 ? YOLO_CFG(256, 64, 4, 1, 32, 3, true) : YOLO_CFG(256, 64, 4, 1, 32, 3, false);
+  if (!fast64) return fast32 ? YOLO_CFG(128, 128, 2, 2, 32, 3, true) : YOLO_CFG(128, 128, 2, 2, 32, 3, false);
+  // 256x256 (8 waves, one block per CU) halves the operand traffic per FLOP but needs enough tiles to fill
+  // the 256 CUs; otherwise 128x128 (4 waves, two blocks per CU).  Measured on MI355X, see DESIGN.md.
+  int pick = variant;
+  if (conv_variant_override < 0) {
+    const long tiles256 = ((M + 255) / 256) * (d.cout / 256);
+    pick = (d.cout % 256 == 0 && tiles256 >= 160) ? 5 : 0;
+  }
+  switch (pick) {
+    case 3: return YOLO_CFG(256, 128, 4, 2, 64, 2, true);
+    case 5: return YOLO_CFG(256, 256, 4, 2, 64, 2, true);
+    default: return YOLO_CFG(128, 128, 2, 2, 64, 2, true);
+  }
+#undef YOLO_CFG
 }
 
 extern "C" int yolo_conv2d_fwd(const void* x, const void* w_packed, const float* bias, const void* residual, void* y,

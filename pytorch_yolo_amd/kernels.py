@@ -40,7 +40,7 @@ def pack_conv_weight(w_oihw: torch.Tensor, bias: torch.Tensor | None, cin: int):
     k = (kh*ks + kw)*cin + c ; cin >= w.shape[1] pads extra input channels with zeros."""
     w = w_oihw.detach().float().cpu()
     cout, cin_w, k, _ = w.shape
-    kpad, cout_pad = roundup(k * k * cin, 32), roundup(cout, 128)
+    kpad, cout_pad = roundup(k * k * cin, 64), roundup(cout, 128)
     packed = torch.zeros((cout_pad, k * k, cin), dtype=torch.float32)
     packed[:cout, :, :cin_w] = w.permute(0, 2, 3, 1).reshape(cout, k * k, cin_w)
     packed = torch.nn.functional.pad(packed.reshape(cout_pad, k * k * cin), (0, kpad - k * k * cin))

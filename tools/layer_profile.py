@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Per-layer timing of one forward (HIP events around each recorded op, median of R repeats).
+
+    python tools/layer_profile.py --workload spp --bs 32 [--repeat 5]
+Prints one row per launch: kind, GEMM view (M, N, K), ms, TFLOP/s, algorithmic GB/s.
+"""
+import argparse
+import ctypes as C
+import os
+import statistics
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import importlib.util
+spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+bench = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(bench)
+from pytorch_yolo_amd import kernels as K
+from pytorch_yolo_amd._lib import OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_SPP, YoloOp
+from pytorch_yolo_amd.utils.synthetic import synth_images, synth_state_dict
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="spp")
+    ap.add_argument("--bs", type=int, default=0)
+    ap.add_argument("--repeat", type=int, default=5)
+    args = ap.parse_args()
+    wl = bench.WORKLOADS[args.workload]
+    bs = args.bs or wl["bs"]
+    dev = torch.device("cuda", 0)
+    model = wl["cls"](**wl["kw"]).eval()
+    model.load_state_dict(synth_state_dict(model.state_dict(), 1234, n_class=80))
+    model = model.to(dev)
+    x = synth_images(bs, wl["hw"], wl["hw"], 0).to(dev)
+    plan = model.plan_for(x)
+    K.pack_input(x, plan.input_buffer)
+    K.run_ops(plan.op_array, plan.n_ops)
+    torch.cuda.synchronize()
+    times = [[] for _ in range(plan.n_ops)]
+    for _ in range(args.repeat):
+        for i in range(plan.n_ops):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            one = C.cast(C.byref(plan.op_array, i * C.sizeof(YoloOp)), C.POINTER(YoloOp))
+            e0.record()
+            K.run_ops(one, 1)
+            e1.record()
+            e1.synchronize()
+            times[i].append(e0.elapsed_time(e1))
+    tot_ms = tot_fl = 0.0
+    print(f"{'#':>3} {'kind':7} {'M':>9} {'N':>5} {'K':>5} {'k':>1} {'s':>1} {'ms':>8} {'TFLOP/s':>8} {'GB/s':>7}  flags")
+    for i in range(plan.n_ops):
+        op = plan.op_array[i]
+        d = op.conv
+        ms = statistics.median(times[i])
+        tot_ms += ms
+        if op.kind == OP_CONV:
+            M, N, Kd = d.n * d.ho * d.wo, d.cout, d.ksize * d.ksize * d.cin
+            fl = 2.0 * M * N * Kd
+            by = d.n * d.h * d.w * d.cin * 2 + M * N * (4 if d.out_dtype else 2) * (4 if d.upsample2x else 1) + N * Kd * 2
+            if op.residual:
+                by += M * N * 2
+            if op.y_aux:
+                by += M * N * 2
+            tot_fl += fl
+            flags = ("res " if op.residual else "") + ("aux " if op.y_aux else "") + ("up " if d.upsample2x else "") + ("f32" if d.out_dtype else "")
+            print(f"{i:3d} {'conv':7} {M:9d} {N:5d} {Kd:5d} {d.ksize:1d} {d.stride:1d} {ms:8.4f} {fl / ms / 1e9:8.1f} {by / ms / 1e6:7.0f}  {flags}")
+        else:
+            kind = {OP_MAXPOOL: "pool", OP_SPP: "spp", OP_DWCONV: "dwconv"}[op.kind]
+            by = d.n * d.h * d.w * d.cin * 2 * (4 if op.kind == OP_SPP else 2)
+            print(f"{i:3d} {kind:7} {d.n * d.h * d.w:9d} {d.cin:5d} {'':5} {d.ksize:1d} {d.stride:1d} {ms:8.4f} {'':8} {by / ms / 1e6:7.0f}")
+    print(f"total {tot_ms:.3f} ms  conv {tot_fl / 1e12:.3f} TFLOP -> {tot_fl / tot_ms / 1e9:.1f} TFLOP/s over the per-op sum")
+
+
+if __name__ == "__main__":
+    main()
