@@ -131,12 +131,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel
     px_hi0[it] = oh * d.stride - d.pad;
     px_wi0[it] = ow * d.stride - d.pad;
     px_base[it] = ((b * d.h + px_hi0[it]) * d.w + px_wi0[it]) * d.in_c_total + d.in_c_offset;
-    uint32_t mask = 0;
-    for (int t = 0; t < ntaps; ++t) {
-      const int dh = d.ksize == 3 ? t / 3 : 0, dw = d.ksize == 3 ? t - 3 * dh : 0;
-      const bool in = (unsigned)(px_hi0[it] + dh) < (unsigned)d.h && (unsigned)(px_wi0[it] + dw) < (unsigned)d.w;
-      mask |= (uint32_t)(ok && in) << t;
+    // bit t = kh*3+kw set iff that tap lies inside the image: outer product of 3 row bits and 3 column bits
+    uint32_t mask;
+    if (d.ksize == 3) {
+      uint32_t cb = 0, rb = 0;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        cb |= (uint32_t)((unsigned)(px_wi0[it] + t) < (unsigned)d.w) << t;
+        rb |= (uint32_t)((unsigned)(px_hi0[it] + t) < (unsigned)d.h) << t;
+      }
+      mask = ((rb & 1) ? cb : 0) | ((rb & 2) ? cb << 3 : 0) | ((rb & 4) ? cb << 6 : 0);
+    } else {
+      mask = ((unsigned)px_hi0[it] < (unsigned)d.h && (unsigned)px_wi0[it] < (unsigned)d.w) ? 1u : 0u;
     }
+    if (!ok) mask = 0;
     px_mask[it] = mask;
     if (FAST) px_base[it] = (px_base[it] + chunk * 8) * 2;   // byte offset of this lane's chunk at tap (0,0)
   }
@@ -427,7 +435,7 @@ int launch_cfg(const ConvArgs& a, hipStream_t s) {
   const int m_tiles = (a.M + BM - 1) / BM;
   ConvArgs b = a;
   b.n_tiles = (a.d.cout + BN - 1) / BN;
-  b.steps = a.d.kpad / BK;
+  b.steps = (a.d.ksize * a.d.ksize * a.d.cin + BK - 1) / BK;   // kpad >= steps*BK: the K tail is zero-padded
   const long grid = (long)m_tiles * b.n_tiles;
   if (grid > 0x7fffffffL) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv grid too large");
   hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, BK, NS, FAST, LDS_EPI>), dim3((unsigned)grid),
@@ -491,8 +499,8 @@ int yolo_conv2d_launch(const void* x, const void* w, const float* bias, const vo
 #define YOLO_CFG(BM, BN, WM, WN, BK, NS, FASTV)                                                           \
   (epi ? launch_cfg<BM, BN, WM, WN, BK, NS, FASTV, true>(a, s) : launch_cfg<BM, BN, WM, WN, BK, NS, FASTV, false>(a, s))
   if (d.cout <= 32)
-    return fast32 ? launch_cfg<256, 32, 4, 1, 32, 3, true, false>(a, s) : launch_cfg<256, 32, 4, 1, 32, 3, false, false>(a, s);
-  if (d.cout <= 64) return fast32 ? YOLO_CFG(256, 64, 4, 1, 32, 3, true) : YOLO_CFG(256, 64, 4, 1, 32, 3, false);
+    return fast32 ? launch_cfg<256, 32, 4, 1, 32, 2, true, false>(a, s) : launch_cfg<256, 32, 4, 1, 32, 2, false, false>(a, s);
+  if (d.cout <= 64) return fast32 ? YOLO_CFG(256, 64, 4, 1, 32, 2, true) : YOLO_CFG(256, 64, 4, 1, 32, 2, false);
   if (!fast64) return fast32 ? YOLO_CFG(128, 128, 2, 2, 32, 3, true) : YOLO_CFG(128, 128, 2, 2, 32, 3, false);
   // 256x256 (8 waves, one block per CU) halves the operand traffic per FLOP but needs enough tiles to fill
   // the 256 CUs; otherwise 128x128 (4 waves, two blocks per CU).  Measured on MI355X, see DESIGN.md.
