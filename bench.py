@@ -44,21 +44,6 @@ WORKLOADS = {
 CONF_THRES, NMS_THRES = 0.1, 0.5
 
 
-def conv_flops(plan) -> float:
-    """Exact algorithmic FLOPs of the recorded conv launches (2*M*Cout*K, logical sizes)."""
-    from pytorch_yolo_amd._lib import OP_CONV, OP_DWCONV
-    total = 0.0
-    for i in range(plan.n_ops):
-        op = plan.op_array[i]
-        d = op.conv
-        if op.kind == OP_CONV:
-            cin = 3 if (d.cin == 8 and i == 0) else d.cin
-            total += 2.0 * d.n * d.ho * d.wo * d.cout * d.ksize * d.ksize * cin
-        elif op.kind == OP_DWCONV:
-            total += 2.0 * d.n * d.ho * d.wo * d.cin * 9
-    return total
-
-
 def host_cores() -> int:
     """Threads the CPU baseline may use: the cgroup CPU quota if there is one, else the affinity
     mask, capped at 16 (a 1-GPU box's CPU share; more threads than that only thrash)."""
@@ -115,7 +100,7 @@ def main():
     ap.add_argument("--workload", default="spp", choices=list(WORKLOADS))
     ap.add_argument("--bs", type=int, default=0, help="images per GPU (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="replay the forward as a captured HIP graph")
+    ap.add_argument("--streams", type=int, default=2, help="concurrent sub-batch streams per GPU (1 = off)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -134,6 +119,7 @@ def main():
     model = wl["cls"](**wl["kw"]).eval()
     model.load_state_dict(synth_state_dict(model.state_dict(), 1234, n_class=80))
     model = model.to(dev)
+    model.n_streams = args.streams
     x = synth_images(bs, wl["hw"], wl["hw"], seed=rank).to(dev)      # per-rank images, resident in HBM
 
     plan = model.plan_for(x)
@@ -143,7 +129,7 @@ def main():
                torch.empty((bs, cap), dtype=torch.int32, device=dev),
                torch.empty((bs,), dtype=torch.int32, device=dev))
     io, ps = plan.new_outputs()
-    flops_step = conv_flops(plan)
+    flops_step = plan.conv_flops()
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * (args.steps + args.warmup))]
     conv_ms = []
@@ -151,12 +137,7 @@ def main():
     def step(i):
         """pack -> 76 conv launches (+pools) -> 3 decodes -> NMS (-> all-gather). HIP events bracket the
         conv launch list on the stream it is launched on (torch's current stream)."""
-        K.pack_input(x, plan.input_buffer)
-        ev[2 * i].record()
-        K.run_ops(plan.op_array, plan.n_ops)
-        ev[2 * i + 1].record()
-        for hd, p in zip(plan.heads, ps):
-            K.decode(hd["sym"].buf.tensor, hd["anchors"], nc, hd["stride"], io, hd["row"], p)
+        plan._launch(x, io, ps, timing=(ev[2 * i], ev[2 * i + 1]))
         nms_raw(io, CONF_THRES, NMS_THRES, out=nms_out)
         if world > 1:
             return gather_detections(nms_out[0], nms_out[2])
@@ -206,7 +187,8 @@ def main():
             "config": {"workload": wl["name"], "images_per_gpu": bs, "global_batch": bs * world,
                        "n_class": nc, "conf_thres": CONF_THRES, "nms_thres": NMS_THRES,
                        "sharding": f"batch x{world}" + (" + RCCL all-gather of detections" if world > 1 else ""),
-                       "mean_detections_per_image": round(sum(n_dets) / max(1, len(n_dets)), 1)},
+                       "mean_detections_per_image": round(sum(n_dets) / max(1, len(n_dets)), 1),
+                       "streams_per_gpu": getattr(plan, "streams", None) and len(plan.streams) or 1},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "kernel": "conv_igemm_bf16_kernel (all conv launches of one forward)",

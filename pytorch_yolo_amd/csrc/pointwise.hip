@@ -167,19 +167,17 @@ struct DecodeArgs {
 };
 
 __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= a.total) return;
-  const int no = a.nc + 5;
-  const int k = (int)(t % no);
-  long cell = t / no;
-  const int gx = (int)(cell % a.nx);
-  cell /= a.nx;
-  const int gy = (int)(cell % a.ny);
-  cell /= a.ny;
-  const int an = (int)(cell % a.na);
-  const long b = cell / a.na;
-  const float raw = a.head[((b * a.ny + gy) * a.nx + gx) * a.head_ct + an * no + k];
-  if (a.p) a.p[t] = raw;
+  // grid.y = image*na + anchor; grid.x covers the ny*nx*(5+nc) elements of that plane (32-bit index math)
+  const uint32_t no = (uint32_t)a.nc + 5u;
+  const uint32_t plane = (uint32_t)a.ny * (uint32_t)a.nx * no;
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= plane) return;
+  const uint32_t b = blockIdx.y / (uint32_t)a.na, an = blockIdx.y - b * (uint32_t)a.na;
+  const uint32_t cell = t / no, k = t - cell * no;
+  const uint32_t gy = cell / (uint32_t)a.nx, gx = cell - gy * (uint32_t)a.nx;
+  const float raw = a.head[((size_t)b * a.ny * a.nx + cell) * a.head_ct + an * no + k];
+  const size_t pidx = ((size_t)b * a.na + an) * plane + t;
+  if (a.p) a.p[pidx] = raw;
   float v;
   if (k < 2) {
     v = (1.f / (1.f + expf(-raw)) + (float)(k == 0 ? gx : gy)) * a.stride;   // :91,:94
@@ -189,8 +187,8 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
     v = 1.f / (1.f + expf(-raw));                                             // :93
     if (a.nc == 1 && k == 5) v = 1.f;                                         // :95-96
   }
-  const long row = a.io_row_offset + ((long)an * a.ny + gy) * a.nx + gx;
-  a.io[(b * a.io_rows_total + row) * no + k] = v;
+  const size_t row = (size_t)a.io_row_offset + (size_t)an * a.ny * a.nx + cell;
+  a.io[((size_t)b * a.io_rows_total + row) * no + k] = v;
 }
 
 inline unsigned blocks_for(long total) { return (unsigned)((total + 255) / 256); }
@@ -276,6 +274,8 @@ extern "C" int yolo_decode_fwd(const float* head, int head_c_total, const float*
     a.anchor_h[i] = anchors_px[2 * i + 1] / stride_px;
   }
   a.total = (long)bs * na * ny * nx * (5 + nc);
-  hipLaunchKernelGGL(decode_kernel, dim3(blocks_for(a.total)), dim3(256), 0, (hipStream_t)s, a);
+  const long plane = (long)ny * nx * (5 + nc);
+  YOLO_REQUIRE(plane < 0x7fffffffL && (long)bs * na <= 65535, "decode: head too large");
+  hipLaunchKernelGGL(decode_kernel, dim3(blocks_for(plane), (unsigned)(bs * na)), dim3(256), 0, (hipStream_t)s, a);
   return yolo_check_launch("yolo_decode_fwd");
 }

@@ -312,12 +312,33 @@ class Plan:
     def input_buffer(self) -> torch.Tensor:
         return self.rec.input.buf.tensor
 
-    def _launch(self, x: torch.Tensor, io: torch.Tensor, ps):
+    def _launch(self, x: torch.Tensor, io: torch.Tensor, ps, timing=None):
+        """pack -> layer list -> decodes on the current stream.  ``timing`` = (start, end) torch events
+        recorded around the layer list (bench.py's roofline measurement)."""
         K.pack_input(x, self.input_buffer)
+        if timing is not None:
+            timing[0].record()
         K.run_ops(self.op_array, self.n_ops)
+        if timing is not None:
+            timing[1].record()
         for hd, p in zip(self.heads, ps):
             s = hd["sym"]
             K.decode(s.buf.tensor, hd["anchors"], self.n_class, hd["stride"], io, hd["row"], p)
+
+    def conv_flops(self) -> float:
+        """Exact algorithmic FLOPs of the recorded conv launches (2*M*Cout*K with logical sizes)."""
+        total = 0.0
+        first = True
+        for i in range(self.n_ops):
+            op = self.op_array[i]
+            d = op.conv
+            if op.kind == OP_CONV:
+                cin = self.rec.c_in if first else d.cin      # the first layer's 3 -> 8 channel pad is not work
+                first = False
+                total += 2.0 * d.n * d.ho * d.wo * d.cout * d.ksize * d.ksize * cin
+            elif op.kind == OP_DWCONV:
+                total += 2.0 * d.n * d.ho * d.wo * d.cin * 9
+        return total
 
     def new_outputs(self):
         n = self.rec.input.n
@@ -356,6 +377,70 @@ class Plan:
         self._static_x.copy_(x)
         self._graph.replay()
         return self._static_out
+
+
+class StreamedPlan:
+    """The batch split into S contiguous sub-batches, each with its own Plan, run on S HIP streams.
+
+    Images are independent, so results are identical; what changes is occupancy: the heavy layers launch
+    200..800 tiles of 256x256 on 256 CUs, i.e. 1.56 or 3.1 "rounds", and the partial last round leaves a
+    quarter of the chip idle.  Two kernels from two streams fill each other's tails (measured: -9.5 % on
+    the SPP-640 bs=32 layer list; four streams are no better than two)."""
+
+    def __init__(self, make_plan, bs: int, n_streams: int, device):
+        assert bs % n_streams == 0
+        self.sub = bs // n_streams
+        self.subs = [make_plan(self.sub) for _ in range(n_streams)]
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
+        self._marks = [torch.cuda.Event() for _ in range(n_streams)]
+        p0 = self.subs[0]
+        self.device, self.n_class, self.img_size = device, p0.n_class, p0.img_size
+        self.heads, self.rows_total = p0.heads, p0.rows_total
+        self.bs = bs
+        self._graph = None
+
+    def new_outputs(self):
+        no = self.n_class + 5
+        io = torch.empty((self.bs, self.rows_total, no), dtype=torch.float32, device=self.device)
+        ps = tuple(torch.empty((self.bs, hd["na"], hd["sym"].h, hd["sym"].w, no), dtype=torch.float32, device=self.device)
+                   for hd in self.heads)
+        return io, ps
+
+    def _launch(self, x, io, ps, timing=None):
+        cur = torch.cuda.current_stream()
+        if timing is not None:
+            timing[0].record(cur)
+        for i, (pl, st) in enumerate(zip(self.subs, self.streams)):
+            lo, hi = i * self.sub, (i + 1) * self.sub
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                K.pack_input(x[lo:hi], pl.input_buffer)
+                K.run_ops(pl.op_array, pl.n_ops)
+                self._marks[i].record(st)
+                for hd, p in zip(pl.heads, ps):
+                    K.decode(hd["sym"].buf.tensor, hd["anchors"], self.n_class, hd["stride"], io[lo:hi], hd["row"], p[lo:hi])
+        if timing is not None:
+            for m in self._marks:
+                cur.wait_event(m)
+            timing[1].record(cur)          # every stream's layer list is done (decodes may still run)
+        for st in self.streams:
+            cur.wait_stream(st)
+
+    def run(self, x):
+        io, ps = self.new_outputs()
+        self._launch(x, io, ps)
+        return io, ps
+
+    run_graph = None   # bound below (shares Plan.run_graph's capture logic)
+
+    def conv_flops(self) -> float:
+        return sum(p.conv_flops() for p in self.subs)
+
+    def activation_bytes(self) -> int:
+        return sum(p.activation_bytes() for p in self.subs)
+
+
+StreamedPlan.run_graph = Plan.run_graph
 
 
 def _sym_to_nchw(s: Sym) -> torch.Tensor:

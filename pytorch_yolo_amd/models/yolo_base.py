@@ -117,6 +117,7 @@ class YOLOBase(nn.Module):
         self.encoder = None
         self._plans = {}
         self.use_hip_graph = False
+        self.n_streams = 2          # sub-batches run concurrently on this many HIP streams (engine.StreamedPlan)
 
     def _create_yolo_layers(self, device="cpu"):
         """One YOLOLayer per anchor group, in order (yolo_base.py:117-136)."""
@@ -151,13 +152,16 @@ class YOLOBase(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("pytorch_yolo_amd runs on a ROCm device only: move the input to cuda "
                                "(there is no CPU fallback)")
-        key = (tuple(x.shape), x.device)
+        bs, c, h, w = x.shape
+        n_streams = self.n_streams if (self.n_streams > 1 and bs % self.n_streams == 0 and bs // self.n_streams >= 4) else 1
+        key = (tuple(x.shape), x.device, n_streams)
         plan = self._plans.get(key)
         if plan is None:
-            bs, c, h, w = x.shape
-            rec = engine.Recorder(bs, c, h, w)
-            self._trace(rec, rec.input)
-            plan = engine.Plan(rec, x.device, self.n_class, max(h, w))    # img_size, yolov3_spp.py:142
+            def make(sub_bs):
+                rec = engine.Recorder(sub_bs, c, h, w)
+                self._trace(rec, rec.input)
+                return engine.Plan(rec, x.device, self.n_class, max(h, w))    # img_size, yolov3_spp.py:142
+            plan = make(bs) if n_streams == 1 else engine.StreamedPlan(make, bs, n_streams, x.device)
             self._plans[key] = plan
         return plan
 

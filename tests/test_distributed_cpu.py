@@ -1,0 +1,56 @@
+"""world_size-2 gloo test of the only collective on the path: the all-gather of per-rank detections."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pytorch_yolo_amd.distributed import gather_detections, shard_bounds, split_gathered
+    bs_local, cap = 3, 16
+    g = torch.Generator().manual_seed(100 + rank)
+    dets = torch.rand(bs_local, cap, 7, generator=g)
+    count = torch.tensor([2 + rank, 0, 5], dtype=torch.int32)
+    all_dets, all_count = gather_detections(dets, count, gather_cap=8)
+    out = split_gathered(all_dets, all_count)
+    # every rank reconstructs the same global list, rank-major
+    assert all_count.tolist() == [2, 0, 5, 3, 0, 5]
+    assert out[1] is None and out[4] is None and [len(o) for o in out if o is not None] == [2, 5, 3, 5]
+    mine = out[rank * bs_local]
+    assert torch.equal(mine, dets[0, :2 + rank])
+    other = 1 - rank
+    g2 = torch.Generator().manual_seed(100 + other)
+    assert torch.equal(out[other * bs_local + 2], torch.rand(bs_local, cap, 7, generator=g2)[2, :5])
+    # overflow of the gather capacity is an error, never a silent truncation
+    try:
+        split_gathered(*gather_detections(dets, torch.tensor([9, 0, 0], dtype=torch.int32), gather_cap=8))
+        ok = False
+    except RuntimeError:
+        ok = True
+    assert ok
+    lo, hi = shard_bounds(7, world, rank)
+    ret[rank] = (lo, hi)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allgather_world2():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    [p.start() for p in procs]
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert dict(ret) == {0: (0, 4), 1: (4, 7)}

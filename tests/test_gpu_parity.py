@@ -335,6 +335,27 @@ def test_forward_idempotent_and_graph_replay():
     assert all(torch.equal(a, b) for a, b in zip(p1, p3))
 
 
+def test_concurrent_streams_give_identical_results():
+    """engine.StreamedPlan: sub-batches on 2 HIP streams == one launch list, bit for bit."""
+    from pytorch_yolo_amd.utils.synthetic import synth_images
+    case = C.MODEL_CASES["spp_small"]
+    model, sd, _ = build_case(case)
+    x = synth_images(8, 64, 64, 3).to(DEV)
+    model = model.to(DEV)
+    with torch.no_grad():
+        model.n_streams = 1
+        io1, p1 = model(x)
+        model.n_streams = 2
+        io2, p2 = model(x)
+        assert type(model.plan_for(x)).__name__ == "StreamedPlan"
+        model.use_hip_graph = True
+        io3, _ = model(x)
+        io3 = io3.clone()
+        io4, _ = model(x)
+    assert torch.equal(io1, io2) and all(torch.equal(a, b) for a, b in zip(p1, p2))
+    assert torch.equal(io1, io3) and torch.equal(io1, io4)
+
+
 def test_cpu_input_fails_loudly():
     case = C.MODEL_CASES["tiny_small"]
     model, sd, x = build_case(case)

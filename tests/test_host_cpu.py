@@ -1,0 +1,166 @@
+"""CPU-only checks: the C-ABI library loads and exports everything include/yolo_hip.h declares, the host
+mirror keeps the reference's state_dict layout, the planner fuses what DESIGN.md says it fuses, the host-side
+weight preparation matches the oracle, and the product refuses to run without a GPU."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import _cases as C
+from pytorch_yolo_amd import YOLOv3SPP, YOLOv3Tiny, YOLOv3TinyMobile, _lib, engine
+from pytorch_yolo_amd import kernels as K
+from pytorch_yolo_amd._lib import OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_SPP
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "yolo_hip.h")).read()
+    return re.findall(r"YOLO_API\s+[\w\s\*]+?\b(yolo_\w+)\s*\(", text)
+
+
+def test_library_exports_every_declared_symbol():
+    names = _header_functions()
+    assert len(names) >= 12 and len(set(names)) == len(names)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/yolo_hip.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), "ctypes table and header disagree"
+    assert _lib.load().yolo_abi_version() == 1
+
+
+def test_struct_layout_matches_header():
+    # 23 int32 fields in YoloConvDesc; YoloOp = 2 int32 + 6 pointers + desc
+    assert ctypes.sizeof(_lib.YoloConvDesc) == 23 * 4
+    assert ctypes.sizeof(_lib.YoloOp) == 8 + 6 * 8 + 23 * 4 + 4   # tail padding to 8-byte alignment
+    text = open(os.path.join(ROOT, "include", "yolo_hip.h")).read()
+    body = text[text.index("typedef struct YoloConvDesc {"):text.index("} YoloConvDesc;")]
+    fields = re.findall(r"\b([a-z_0-9]+)\s*[,;]", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
+    assert fields == [f for f, _ in _lib.YoloConvDesc._fields_]
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    lib = _lib.load()
+    d = _lib.YoloConvDesc()
+    rc = lib.yolo_conv2d_fwd(None, None, None, None, None, None, ctypes.byref(d), None)
+    assert rc == -1 and b"null pointer" in lib.yolo_last_error()
+    assert lib.yolo_nms_workspace_bytes(32, 25200, 80) > 32 * 25200 * 8
+    assert lib.yolo_nms_workspace_bytes(0, 1, 1) == 0
+
+
+def test_c_weight_packer_matches_torch_packer():
+    lib = _lib.load()
+    w = torch.randn(5, 3, 3, 3)
+    wp, bp, kpad, cout_pad = K.pack_conv_weight(w, torch.arange(5.), 8)
+    out = np.zeros((cout_pad, kpad), dtype=np.uint16)
+    wc = w.contiguous().numpy()
+    rc = lib.yolo_pack_conv_weight_f32(wc.ctypes.data_as(ctypes.c_void_p), 5, 3, 3, 8, cout_pad, kpad,
+                                       out.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0
+    assert np.array_equal(out, wp.view(torch.int16).numpy().view(np.uint16))
+    assert (kpad, cout_pad) == (128, 128) and bp[:5].tolist() == [0, 1, 2, 3, 4] and float(bp[5:].abs().sum()) == 0
+    # layout: k = (kh*3 + kw)*cin + c
+    assert float(wp[2, (1 * 3 + 2) * 8 + 1]) == float(w[2, 1, 1, 2].to(torch.bfloat16))
+
+
+def test_state_dict_layout_matches_reference():
+    keys = json.load(open(os.path.join(ROOT, "tests", "golden", "state_keys.json")))
+    for fam, model in (("tiny", YOLOv3Tiny(kernels_divider=2)),
+                       ("spp", YOLOv3SPP(kernels_divider=4, anchors=C.SPP_ANCHORS))):
+        sd = model.state_dict()
+        assert {k: list(v.shape) for k, v in sd.items()} == keys[fam]
+        assert list(sd) == list(keys[fam])                       # same order too
+        model.fuse()
+        assert {k: list(v.shape) for k, v in model.state_dict().items()} == keys[fam + "_fused"]
+
+
+def test_fold_bn_matches_oracle():
+    from oracle.blocks import fold_bn
+    from pytorch_yolo_amd.utils.torch_utils import fold_conv_bn
+    w, g, b, m, v = torch.randn(6, 4, 3, 3), torch.rand(6) + 0.5, torch.randn(6), torch.randn(6), torch.rand(6) + 0.5
+    w1, b1 = fold_conv_bn(w, None, g, b, m, v, 1e-5)
+    w2, b2 = fold_bn(w, g, b, m, v)
+    torch.testing.assert_close(w1, w2, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(b1, b2, rtol=1e-6, atol=1e-7)
+
+
+def _dry_plan(model, hw, bs=1):
+    rec = engine.Recorder(bs, 3, hw, hw)
+    model._trace(rec, rec.input)
+    return engine.Plan(rec, torch.device("cpu"), model.n_class, hw)
+
+
+def _ops(plan):
+    return [plan.op_array[i] for i in range(plan.n_ops)]
+
+
+def test_planner_spp_fusions():
+    plan = _dry_plan(YOLOv3SPP(anchors=C.SPP_ANCHORS).eval(), 640)
+    ops = _ops(plan)
+    kinds = [o.kind for o in ops]
+    assert kinds.count(OP_CONV) == 76 and kinds.count(OP_SPP) == 1 and len(ops) == 77      # no add / cat / upsample launches
+    convs = [o for o in ops if o.kind == OP_CONV]
+    assert sum(1 for o in convs if o.residual) == 23                                        # every Add is an epilogue
+    assert all(o.residual == o.y for o in convs if o.residual)                              # ... written in place
+    aux = [o for o in convs if o.y_aux]
+    assert [(o.conv.aux_c_total, o.conv.aux_c_offset) for o in aux] == [(384, 128), (768, 256)]   # pre-add routes -> concat slices
+    ups = [o for o in convs if o.conv.upsample2x]
+    assert [(o.conv.out_c_total, o.conv.out_c_offset) for o in ups] == [(768, 0), (384, 0)]
+    spp_in = [o for o in convs if o.conv.out_c_total == 2048]
+    assert len(spp_in) == 1 and spp_in[0].conv.out_c_offset == 1536                         # x lands in the last SPP slice
+    heads = [o for o in convs if o.conv.out_dtype == 1]
+    assert [(o.conv.cout, o.conv.out_c_total) for o in heads] == [(255, 256)] * 3
+    assert plan.rows_total == 25200 and [h["row"] for h in plan.heads] == [0, 1200, 6000]
+    assert [h["stride"] for h in plan.heads] == [32.0, 16.0, 8.0]
+
+
+def test_planner_tiny_and_mobile():
+    plan = _dry_plan(YOLOv3Tiny().eval(), 416)
+    kinds = [o.kind for o in _ops(plan)]
+    assert kinds.count(OP_CONV) == 13 and kinds.count(OP_MAXPOOL) == 6
+    pools = [o.conv for o in _ops(plan) if o.kind == OP_MAXPOOL]
+    assert (pools[-1].ksize, pools[-1].stride, pools[-1].pad, pools[-1].upsample2x) == (2, 1, 1, 2)   # dilated special
+    # route1 is produced straight into the concat buffer [route1(256) | upsampled(128)]
+    cat_writers = [(o.conv.out_c_offset, o.conv.upsample2x) for o in _ops(plan) if o.kind == OP_CONV and o.conv.out_c_total == 384]
+    assert sorted(cat_writers) == [(0, 0), (256, 1)]
+    assert plan.rows_total == 2535 and [h["stride"] for h in plan.heads] == [16.0, 32.0]
+    plan = _dry_plan(YOLOv3TinyMobile().eval(), 416)
+    kinds = [o.kind for o in _ops(plan)]
+    assert kinds.count(OP_DWCONV) == 17 and kinds.count(OP_CONV) == 40
+    assert sum(1 for o in _ops(plan) if o.kind == OP_CONV and o.residual) == 10          # MobileNetV2 identity shortcuts
+
+
+def test_unsupported_widths_fail_loudly():
+    m = YOLOv3SPP(anchors=C.SPP_ANCHORS, kernels_divider=8).eval()
+    with pytest.raises(RuntimeError, match="multiple of 8"):
+        _dry_plan(m, 64)
+    with pytest.raises(NotImplementedError):
+        YOLOv3Tiny(onnx=True, in_shape=(1, 3, 64, 64))
+
+
+def test_no_cpu_fallback():
+    m = YOLOv3Tiny(kernels_divider=8, n_class=3).eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.rand(1, 3, 64, 64))
+    from pytorch_yolo_amd import non_max_suppression
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        non_max_suppression(torch.rand(1, 10, 8))
+    import pytorch_yolo_amd
+    src = "".join(open(os.path.join(os.path.dirname(pytorch_yolo_amd.__file__), f)).read()
+                  for f in ("engine.py", "kernels.py", "_lib.py", "distributed.py"))
+    assert "oracle" not in src, "the product must never import the oracle"
+
+
+def test_synthetic_generator_is_deterministic_and_order_free():
+    from pytorch_yolo_amd.utils.synthetic import synth_images, synth_state_dict
+    m = YOLOv3Tiny(kernels_divider=8, n_class=3)
+    a = synth_state_dict(m.state_dict(), 11, n_class=3)
+    b = synth_state_dict(dict(reversed(list(m.state_dict().items()))), 11, n_class=3)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    x = synth_images(2, 32, 48, 21)
+    assert x.shape == (2, 3, 32, 48) and 0 <= float(x.min()) and float(x.max()) < 1
+    assert torch.equal(x, synth_images(2, 32, 48, 21))

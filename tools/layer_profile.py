@@ -35,6 +35,7 @@ def main():
     model = wl["cls"](**wl["kw"]).eval()
     model.load_state_dict(synth_state_dict(model.state_dict(), 1234, n_class=80))
     model = model.to(dev)
+    model.n_streams = 1
     x = synth_images(bs, wl["hw"], wl["hw"], 0).to(dev)
     plan = model.plan_for(x)
     K.pack_input(x, plan.input_buffer)
