@@ -18,6 +18,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SOURCES = {
     "runtime.hip": [],
     "conv_igemm.hip": [],
+    "conv3x3_halo.hip": [],
     "pointwise.hip": [],
     "nms.hip": ["-ffp-contract=off"],
 }
@@ -33,7 +34,7 @@ def _stale(out: str, deps) -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    headers = [os.path.join(CSRC, "common.h"),
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_common.h"),
                os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "yolo_hip.h")]
     objs = []
     for src, extra in SOURCES.items():
@@ -44,6 +45,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
             cmd = [HIPCC, *COMMON, *extra, "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
+            for stale in (o, LIB_PATH):          # never leave an out-of-date library behind a failed build
+                if os.path.exists(stale):
+                    os.remove(stale)
             subprocess.run(cmd, check=True)
     if force or _stale(LIB_PATH, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs]

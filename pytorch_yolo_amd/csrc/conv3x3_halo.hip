@@ -1,0 +1,219 @@
+// Halo-staged 3x3 / stride-1 / pad-1 convolution for gfx950 (MI355X), same contract and numerics as
+// conv_igemm.hip (bf16 NHWC in, fp32 MFMA accumulate, fused epilogue) — used for the large feature maps.
+//
+// Why a second kernel: the gather implicit-GEMM stages the pixel operand once PER FILTER TAP (9x the input
+// bytes through the L2 -> LDS path).  On the big maps (>= 80x80) that path, not the matrix pipe, is the
+// limiter (loads-only 0.095 ms vs MFMA-only 0.10 ms vs 0.31 ms total for 64->128 @160^2).
+// Here a block owns a TH x TW output tile of ONE image and stages the (TH+2) x (TW+2) input halo tile once per
+// cin chunk; the nine taps then read it at shifted LDS rows.  Only the weights are streamed per tap.
+//
+//   LDS:  halo [HB][(TH+2)(TW+2) rows][CK ch]   weights ring [2][BN rows][CK ch]     (rows XOR-swizzled)
+//   step s = chunk*9 + tap:   s_waitcnt vmcnt(0) ; s_barrier ; issue weights(s+1) + a slice of halo(chunk+1)
+//                             ; CK/16 x { ds_read_b128 fragments, MFMA 32x32x16 } .
+// Image borders need no masks: halo pixels outside the image are fetched with an out-of-range buffer offset,
+// which makes the LDS-DMA write zeros.
+#include "conv_common.h"
+
+using namespace yolo_conv;
+
+namespace {
+
+template <int TH, int TW, int BN, int WAVES_M, int WAVES_N, int CK, int HB>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv3x3_halo_kernel(const ConvArgs a) {
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int BM = TH * TW;
+  constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N;
+  constexpr int NI = TM / 32, MI = TN / 32;
+  constexpr int ROWB = CK * 2, CPR = CK / 8, RPP = 1024 / ROWB;     // LDS row bytes, chunks per row, rows per 1-KiB piece
+  constexpr int HW2 = TW + 2;
+  constexpr int HP = (TH + 2) * HW2;                                 // halo pixels
+  constexpr int HPIECES = (HP + RPP - 1) / RPP;
+  constexpr int HPT = (HPIECES + NW - 1) / NW;                       // halo pieces per wave
+  constexpr int HALO_B = HPT * NW * 1024;                            // bytes per halo buffer (padded to whole pieces)
+  constexpr int WPIECES = BN / RPP;
+  constexpr int WIT = WPIECES / NW;                                  // weight pieces per wave per tap
+  constexpr int WBUF_B = BN * ROWB;
+  constexpr int RING_B = HB * HALO_B + 2 * WBUF_B;
+  constexpr int LDS_B = RING_B > NW * TM * kEpiPitch ? RING_B : NW * TM * kEpiPitch;   // the epilogue slab reuses it
+  constexpr int KS = CK / 16;
+  static_assert(CK == 32 || CK == 64, "CK");
+  static_assert(TM % 32 == 0 && TN % 32 == 0 && WPIECES % NW == 0 && WIT >= 1, "tile");
+  static_assert(LDS_B <= 160 * 1024 && NW * TM * kEpiPitch <= LDS_B, "LDS");
+
+  __shared__ __attribute__((aligned(16))) char smem[LDS_B];
+  char* const s_halo = smem;
+  char* const s_w = smem + HB * HALO_B;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const YoloConvDesc& d = a.d;
+
+  // work item -> (image, tile row, tile col, cout tile); cout tile fastest so an XCD re-reads its halo from L2
+  const int tiles_x = (d.w + TW - 1) / TW, tiles_y = (d.h + TH - 1) / TH;
+  int b, y0, x0, n0;
+  {
+    int swz = xcd_swizzle(blockIdx.x, gridDim.x);
+    n0 = (swz % a.n_tiles) * BN;
+    swz /= a.n_tiles;
+    x0 = (swz % tiles_x) * TW;
+    swz /= tiles_x;
+    y0 = (swz % tiles_y) * TH;
+    b = swz / tiles_y;
+  }
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+
+  // ---- LDS-DMA source offsets (per lane, constant over the whole K loop; chunk / tap go in the scalar offset)
+  const int frow = lane / CPR;
+  const int fsw = (CK == 32) ? ((lane >> 4) & 3) : (((lane >> 4) + 4 * (wave & 1)) & 7);   // f(row) of this lane's rows
+  const int chunk = (lane & (CPR - 1)) ^ fsw;
+  uint32_t h_off[HPT];
+#pragma unroll
+  for (int it = 0; it < HPT; ++it) {
+    const int hr = (it * NW + wave) * RPP + frow;      // halo row (pixel) this lane fills
+    const int hy = hr / HW2, hx = hr - hy * HW2;
+    const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+    const bool ok = hr < HP && (unsigned)yy < (unsigned)d.h && (unsigned)xx < (unsigned)d.w;
+    h_off[it] = ok ? (uint32_t)((((b * d.h + yy) * d.w + xx) * d.in_c_total + d.in_c_offset + chunk * 8) * 2) : kOobOffset;
+  }
+  uint32_t w_off[WIT];
+#pragma unroll
+  for (int it = 0; it < WIT; ++it)
+    w_off[it] = (uint32_t)(((n0 + (it * NW + wave) * RPP + frow) * d.kpad + chunk * 8) * 2);
+
+  auto issue_halo = [&](int hb, int c, int lo, int hi) {
+    char* const base = s_halo + hb * HALO_B + wave * 1024;
+#pragma unroll
+    for (int it = 0; it < HPT; ++it)
+      if (it >= lo && it < hi && !(a.debug & 1)) lds_dma16s(rx, base + it * (NW * 1024), h_off[it], (uint32_t)c * (CK * 2u));
+  };
+  auto issue_w = [&](int wb, int c, int tap) {
+    char* const base = s_w + wb * WBUF_B + wave * 1024;
+#pragma unroll
+    for (int it = 0; it < WIT; ++it)
+      if (!(a.debug & 2)) lds_dma16s(rw, base + it * (NW * 1024), w_off[it], (uint32_t)((tap * d.cin + c * CK) * 2));
+  };
+
+  // ---- fragment row bases: tile pixel q = wm*TM + j*32 + r32 -> halo row of tap (0,0)
+  const int r32 = lane & 31, khalf = lane >> 5;
+  int hrow0[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int q = wm * TM + j * 32 + r32;
+    hrow0[j] = (q / TW) * HW2 + (q % TW);
+  }
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int n_chunks = d.cin / CK;
+  issue_halo(0, 0, 0, HPT);
+  issue_w(0, 0, 0);
+
+  int wb = 0;
+  for (int c = 0; c < n_chunks; ++c) {
+    const char* const hbuf = s_halo + (HB == 2 ? (c & 1) : 0) * HALO_B;
+    const bool next_chunk = c + 1 < n_chunks;
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();       // stage (c,tap) is in LDS; every wave finished reading stage (c,tap)-1
+      // prefetch: weights of the next step, and 1/9 of the next chunk's halo (HB == 2)
+      if (tap < 8) {
+        issue_w(wb ^ 1, c, tap + 1);
+      } else if (next_chunk) {
+        issue_w(wb ^ 1, c + 1, 0);
+      }
+      if (HB == 2 && next_chunk) issue_halo((c + 1) & 1, c + 1, tap * HPT / 9, (tap + 1) * HPT / 9);
+      const int dh = (tap * 11) >> 5, dw = tap - 3 * dh;
+      const int toff = dh * HW2 + dw;
+      const char* const wbuf = s_w + wb * WBUF_B;
+      if (!(a.debug & 4)) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int g = ks * 2 + khalf;
+          bf16x8 wf[MI], xf[NI];
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            const int R = wn * TN + i * 32 + r32;
+            const int sw = (CK == 32) ? ((R >> 2) & 3) : ((R >> 1) & 7);
+            wf[i] = *reinterpret_cast<const bf16x8*>(wbuf + R * ROWB + ((g ^ sw) << 4));
+          }
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            const int R = hrow0[j] + toff;
+            const int sw = (CK == 32) ? ((R >> 2) & 3) : ((R >> 1) & 7);
+            xf[j] = *reinterpret_cast<const bf16x8*>(hbuf + R * ROWB + ((g ^ sw) << 4));
+          }
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+      }
+      wb ^= 1;
+    }
+    if (HB == 1 && next_chunk) {          // single halo buffer: reload between chunks (only used when it must fit)
+      __builtin_amdgcn_s_barrier();
+      issue_halo(0, c + 1, 0, HPT);
+    }
+  }
+
+  if (a.debug & 8) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" ::"v"(acc[i][j]));
+#endif
+      }
+    return;
+  }
+  __syncthreads();
+  epilogue_lds<MI, NI, TM>(a, acc, smem + wave * (TM * kEpiPitch), lane, n0 + wn * TN, [&](int row) -> long {
+    const int q = wm * TM + row;
+    const int yy = y0 + q / TW, xx = x0 + q % TW;
+    return (yy < d.h && xx < d.w) ? ((long)(b * d.h + yy) * d.w + xx) : -1L;
+  });
+}
+
+template <int TH, int TW, int BN, int WAVES_M, int WAVES_N, int CK, int HB>
+int launch(const ConvArgs& a, hipStream_t s) {
+  ConvArgs b = a;
+  b.n_tiles = (a.d.cout + BN - 1) / BN;
+  const long grid = (long)a.d.n * ((a.d.h + TH - 1) / TH) * ((a.d.w + TW - 1) / TW) * b.n_tiles;
+  if (grid > 0x7fffffffL) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv grid too large");
+  hipLaunchKernelGGL((conv3x3_halo_kernel<TH, TW, BN, WAVES_M, WAVES_N, CK, HB>), dim3((unsigned)grid),
+                     dim3(64 * WAVES_M * WAVES_N), 0, s, b);
+  return yolo_check_launch("yolo_conv2d_fwd(halo)");
+}
+
+}  // namespace
+
+// Returns 1 when the halo kernel does not apply (caller falls back to the gather kernel), else the launch status.
+int yolo_conv::launch_halo3x3(const ConvArgs& a, hipStream_t s) {
+  const YoloConvDesc& d = a.d;
+  if (d.ksize != 3 || d.stride != 1 || d.pad != 1 || d.upsample2x || d.out_dtype != YOLO_DT_BF16) return 1;
+  if (d.cin % 32 != 0 || d.cout % 64 != 0) return 1;
+  // 16x16 output tiles: only worth it when the map tiles well (partial tiles idle lanes) and is large
+  const long tiles = (long)((d.h + 15) / 16) * ((d.w + 15) / 16);
+  if ((double)d.h * d.w < 0.85 * 256.0 * tiles || (long)d.h * d.w < 80 * 80) return 1;
+  if (d.cin % 64 == 0) {
+    const bool one = d.cin == 64;
+    if (d.cout % 256 == 0) return one ? launch<16, 16, 256, 4, 2, 64, 1>(a, s) : launch<16, 16, 256, 4, 2, 64, 2>(a, s);
+    if (d.cout % 128 == 0) return one ? launch<16, 16, 128, 4, 2, 64, 1>(a, s) : launch<16, 16, 128, 4, 2, 64, 2>(a, s);
+    return one ? launch<16, 16, 64, 4, 1, 64, 1>(a, s) : launch<16, 16, 64, 4, 1, 64, 2>(a, s);
+  }
+  const bool one = d.cin == 32;
+  if (d.cout % 128 == 0) return one ? launch<16, 16, 128, 4, 2, 32, 1>(a, s) : launch<16, 16, 128, 4, 2, 32, 2>(a, s);
+  return one ? launch<16, 16, 64, 4, 1, 32, 1>(a, s) : launch<16, 16, 64, 4, 1, 32, 2>(a, s);
+}

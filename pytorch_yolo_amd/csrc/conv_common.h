@@ -1,0 +1,130 @@
+// Pieces shared by the convolution kernels (gather implicit-GEMM and halo-staged 3x3).
+#pragma once
+#include "common.h"
+
+namespace yolo_conv {
+
+constexpr uint32_t kOobOffset = 0xF0000000u;  // > any buffer we accept (host checks < 0xF0000000 bytes)
+
+struct ConvArgs {
+  const bf16_t* x;
+  const bf16_t* w;
+  const float* bias;
+  const bf16_t* res;
+  void* y;
+  bf16_t* aux;
+  YoloConvDesc d;
+  int M;        // n*ho*wo
+  int n_tiles;  // cout tiles
+  int steps;    // kpad / 32
+  uint32_t x_bytes, w_bytes;
+  int debug;    // timing ablations only (YOLO_CONV_DEBUG): 1 no pixel DMA, 2 no weight DMA, 4 no MFMA, 8 no epilogue
+};
+
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, uint32_t voffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16,
+                                           voffset, 0, 0, 0);
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == YOLO_ACT_LEAKY01) return v > 0.f ? v : 0.1f * v;
+  if (act == YOLO_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
+  return v;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+
+__device__ __forceinline__ void lds_dma16s(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, uint32_t voffset,
+                                           uint32_t soffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16,
+                                           voffset, soffset, 0, 0);
+}
+
+
+// LDS-staged epilogue shared by the conv kernels.  acc[MI][NI] are 32x32 MFMA accumulators (lane = pixel
+// column r32 of pixel block j, registers = couts); the wave's TM x (MI*32) tile goes registers -> LDS (fp32,
+// one 32-cout slab per pass) -> coalesced phase in which every lane owns 8 consecutive couts of one pixel,
+// so the residual read, the pre-add copy and the store are 16-byte accesses over whole 64-byte runs per
+// pixel; the sum is formed in fp32 and rounded once.  pix_of(row) maps a row of the wave's pixel tile to
+// the output pixel index (n*ho*wo order) or -1.  `stg` = private per-wave LDS slab of TM*kEpiPitch bytes.
+constexpr int kEpiPitch = 144;   // 32 f32 + 16 B pad
+
+template <int MI, int NI, int TM, typename PixOf>
+__device__ __forceinline__ void epilogue_lds(const ConvArgs& a, const f32x16 (&acc)[MI][NI], char* stg, int lane,
+                                             int cout0, PixOf pix_of) {
+  const YoloConvDesc& d = a.d;
+  const int r32 = lane & 31, khalf = lane >> 5;
+  const int crow = lane >> 2, cchunk = lane & 3;   // coalesced phase: 16 pixel rows x 4 chunks of 8 couts
+  const int hw_out = d.ho * d.wo;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int cbase = cout0 + i * 32;              // first cout of this slab
+    if (cbase >= d.cout) continue;                 // cout % 32 == 0: a slab is all-or-nothing
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int cl = g4 * 8 + khalf * 4;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + cbase + cl);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[i][j][g4 * 4 + e] + bv[e], d.act);
+        *reinterpret_cast<f32x4*>(stg + (j * 32 + r32) * kEpiPitch + cl * 4) = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();               // LDS ops of one wave execute in order
+    const long cofs = cbase + cchunk * 8;
+#pragma unroll
+    for (int pass = 0; pass < TM / 16; ++pass) {
+      const int row = pass * 16 + crow;
+      const long pix = pix_of(row);
+      if (pix >= 0) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * kEpiPitch + cchunk * 32);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * kEpiPitch + cchunk * 32 + 16);
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if (a.aux) {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+          *reinterpret_cast<bf16x8*>(a.aux + pix * d.aux_c_total + d.aux_c_offset + cofs) = o;
+        }
+        if (a.res) {
+          const bf16x8 rv = *reinterpret_cast<const bf16x8*>(a.res + pix * d.res_c_total + d.res_c_offset + cofs);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+        bf16_t* const ybase = reinterpret_cast<bf16_t*>(a.y) + d.out_c_offset + cofs;
+        if (d.upsample2x) {
+          const int b = (int)(pix / hw_out), rem = (int)(pix - (long)b * hw_out);
+          const int oh = rem / d.wo, ow = rem - oh * d.wo;
+          const long op = ((long)(b * 2 * d.ho + 2 * oh)) * (2 * d.wo) + 2 * ow;
+#pragma unroll
+          for (int rep = 0; rep < 4; ++rep)
+            *reinterpret_cast<bf16x8*>(ybase + (op + (rep >> 1) * 2 * d.wo + (rep & 1)) * d.out_c_total) = o;
+        } else {
+          *reinterpret_cast<bf16x8*>(ybase + pix * d.out_c_total) = o;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// XCD-aware block order (bijective for any grid): blocks with equal blockIdx%8 share an XCD / L2 and get a
+// contiguous run of work items.
+__device__ __forceinline__ int xcd_swizzle(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+int launch_halo3x3(const ConvArgs& a, hipStream_t s);   // conv3x3_halo.hip; returns 1 if it does not apply
+
+}  // namespace yolo_conv

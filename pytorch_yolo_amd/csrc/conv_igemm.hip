@@ -16,51 +16,12 @@
 // per-lane SOURCE address (chunk ^= (row>>2)&3) and again on the read.  Zero padding (image border,
 // K tail, M tail) costs nothing: those lanes get a voffset beyond the descriptor's num_records and the
 // hardware writes zeros.  NS-stage LDS ring, counted vmcnt, one raw s_barrier per K step.
-#include "common.h"
+#include "conv_common.h"
 #include <stdlib.h>
 
+using namespace yolo_conv;
+
 namespace {
-
-constexpr uint32_t kOobOffset = 0xF0000000u;  // > any buffer we accept (host checks < 0xF0000000 bytes)
-
-struct ConvArgs {
-  const bf16_t* x;
-  const bf16_t* w;
-  const float* bias;
-  const bf16_t* res;
-  void* y;
-  bf16_t* aux;
-  YoloConvDesc d;
-  int M;        // n*ho*wo
-  int n_tiles;  // cout tiles
-  int steps;    // kpad / 32
-  uint32_t x_bytes, w_bytes;
-  int debug;    // timing ablations only (YOLO_CONV_DEBUG): 1 no pixel DMA, 2 no weight DMA, 4 no MFMA, 8 no epilogue
-};
-
-__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, uint32_t voffset) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16,
-                                           voffset, 0, 0, 0);
-}
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-  if (act == YOLO_ACT_LEAKY01) return v > 0.f ? v : 0.1f * v;
-  if (act == YOLO_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
-  return v;
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-#endif
-}
-
-__device__ __forceinline__ void lds_dma16s(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, uint32_t voffset,
-                                           uint32_t soffset) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16,
-                                           voffset, soffset, 0, 0);
-}
 
 // BM pixels x BN couts block tile, WAVES_M x WAVES_N waves (4 or 8), K step BK (32 or 64), NS-stage LDS ring.
 // Stage s+NS-1 is in flight (LDS-DMA) while stage s is multiplied: the waits are COUNTED
@@ -69,8 +30,8 @@ __device__ __forceinline__ void lds_dma16s(__amdgpu_buffer_rsrc_t rsrc, char* ld
 // FAST (cin % BK == 0): a K step never straddles a filter tap, so tap / channel offset are wave-uniform
 // scalars, the image-border test is one precomputed bit per tap, and the weight address advances through
 // the instruction's scalar offset: ~3 VALU per LDS-DMA instead of ~15.
-// LDS_EPI (bf16 output, cout % 64 == 0): the finished tile goes registers -> LDS -> global so that every
-// store instruction writes whole 128-byte channel runs (16 B per lane) instead of 8-byte fragments.
+// LDS_EPI (bf16 output, cout % 32 == 0): the finished tile goes registers -> LDS (fp32) -> global so that
+// residual read, pre-add copy and store are 16-byte-per-lane accesses over whole channel runs.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int NS, bool FAST, bool LDS_EPI>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel(const ConvArgs a) {
   constexpr int NW = WAVES_M * WAVES_N;
@@ -100,9 +61,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel
   // run of tiles (cout tile fastest) so the pixel tile is re-read from that L2 (bijective for any grid).
   int m0, n0;
   {
-    const int nblk = gridDim.x, bid = blockIdx.x;
-    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int swz = xcd_swizzle(blockIdx.x, gridDim.x);
     const int mt = swz / a.n_tiles;
     m0 = mt * BM;
     n0 = (swz - mt * a.n_tiles) * BN;
@@ -299,66 +258,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel
   // ---- epilogue: lane = pixel (col), registers = couts (row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) ----
   const bool f32_out = d.out_dtype == YOLO_DT_F32;
   if constexpr (LDS_EPI) {
-    static_assert(TN % 64 == 0, "LDS epilogue works on 64-cout slabs");
-    constexpr int EP = 144;                          // staging row pitch: 64 bf16 + 16 B pad (16-B aligned rows)
-    static_assert(NW * TM * EP <= NS * STAGE_B, "staging fits the ring");
+    static_assert(NW * TM * kEpiPitch <= NS * STAGE_B, "staging fits the ring");
     __syncthreads();                                 // every wave is done with the last stage: LDS is free
-    char* const stg = smem + wave * (TM * EP);       // private per-wave slab [TM pixels][64 couts]
-#pragma unroll
-    for (int hp = 0; hp < TN / 64; ++hp) {
-      if (n0 + wn * TN + hp * 64 >= d.cout) continue;   // slab beyond cout (cout % 64 == 0: all or nothing)
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int row = j * 32 + r32;
-        const int pix = m0 + wm * TM + row;
-        const bool pv = pix < a.M;
-#pragma unroll
-        for (int il = 0; il < 2; ++il) {
-          const int i = hp * 2 + il;
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            const int cl = il * 32 + g4 * 8 + khalf * 4;            // cout inside the 64-slab
-            const int c0 = n0 + wn * TN + hp * 64 + cl;
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + c0);
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[i][j][g4 * 4 + e] + bv[e], d.act);
-            if (a.aux && pv) {
-              bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-              *reinterpret_cast<bf16x4*>(a.aux + (long)pix * d.aux_c_total + d.aux_c_offset + c0) = o;
-            }
-            if (a.res && pv) {
-              const bf16x4 rv = *reinterpret_cast<const bf16x4*>(a.res + (long)pix * d.res_c_total + d.res_c_offset + c0);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
-            }
-            bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-            *reinterpret_cast<bf16x4*>(stg + row * EP + cl * 2) = o;
-          }
-        }
-      }
-      __builtin_amdgcn_wave_barrier();               // LDS ops of one wave execute in order
-      bf16_t* const ybase = reinterpret_cast<bf16_t*>(a.y) + d.out_c_offset + n0 + wn * TN + hp * 64 + (lane & 7) * 8;
-#pragma unroll
-      for (int pass = 0; pass < TM / 8; ++pass) {
-        const int row = pass * 8 + (lane >> 3);
-        const int pix = m0 + wm * TM + row;
-        if (pix < a.M) {
-          const u32x4 val = *reinterpret_cast<const u32x4*>(stg + row * EP + (lane & 7) * 16);
-          if (d.upsample2x) {
-            const int b = pix / hw_out, rem = pix - b * hw_out;
-            const int oh = rem / d.wo, ow = rem - oh * d.wo;
-            const long op = ((long)(b * 2 * d.ho + 2 * oh)) * (2 * d.wo) + 2 * ow;
-#pragma unroll
-            for (int rep = 0; rep < 4; ++rep)
-              *reinterpret_cast<u32x4*>(ybase + (op + (rep >> 1) * 2 * d.wo + (rep & 1)) * d.out_c_total) = val;
-          } else {
-            *reinterpret_cast<u32x4*>(ybase + (long)pix * d.out_c_total) = val;
-          }
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
+    epilogue_lds<MI, NI, TM>(a, acc, smem + wave * (TM * kEpiPitch), lane, n0 + wn * TN, [&](int row) -> long {
+      const int pix = m0 + wm * TM + row;
+      return pix < a.M ? (long)pix : -1L;
+    });
   } else {
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
@@ -494,12 +399,17 @@ int yolo_conv2d_launch(const void* x, const void* w, const float* bias, const vo
   a.debug = conv_debug_flags;
   const int variant = conv_variant_override >= 0 ? conv_variant_override : 0;
   const bool fast64 = d.cin % 64 == 0, fast32 = d.cin % 32 == 0;
-  const bool epi = d.out_dtype == YOLO_DT_BF16 && d.cout % 64 == 0 && d.out_c_offset % 8 == 0 && d.out_c_total % 8 == 0 &&
-                   !(conv_debug_flags & 16);
+  const bool epi = d.out_dtype == YOLO_DT_BF16 && d.cout % 32 == 0 && d.out_c_offset % 8 == 0 && d.out_c_total % 8 == 0 &&
+                   (!res || (d.res_c_offset % 8 == 0 && d.res_c_total % 8 == 0)) &&
+                   (!y_aux || (d.aux_c_offset % 8 == 0 && d.aux_c_total % 8 == 0)) && !(conv_debug_flags & 16);
+  if (epi && !(conv_debug_flags & 32) && conv_variant_override < 0) {   // large 3x3/s1 maps: halo-staged kernel
+    a.n_tiles = 0;
+    const int rc = launch_halo3x3(a, s);
+    if (rc != 1) return rc;
+  }
 #define YOLO_CFG(BM, BN, WM, WN, BK, NS, FASTV)                                                           \
   (epi ? launch_cfg<BM, BN, WM, WN, BK, NS, FASTV, true>(a, s) : launch_cfg<BM, BN, WM, WN, BK, NS, FASTV, false>(a, s))
-  if (d.cout <= 32)
-    return fast32 ? launch_cfg<256, 32, 4, 1, 32, 2, true, false>(a, s) : launch_cfg<256, 32, 4, 1, 32, 2, false, false>(a, s);
+  if (d.cout <= 32) return fast32 ? YOLO_CFG(256, 32, 4, 1, 32, 2, true) : YOLO_CFG(256, 32, 4, 1, 32, 2, false);
   if (d.cout <= 64) return fast32 ? YOLO_CFG(256, 64, 4, 1, 32, 2, true) : YOLO_CFG(256, 64, 4, 1, 32, 2, false);
   if (!fast64) return fast32 ? YOLO_CFG(128, 128, 2, 2, 32, 3, true) : YOLO_CFG(128, 128, 2, 2, 32, 3, false);
   // 256x256 (8 waves, one block per CU) halves the operand traffic per FLOP but needs enough tiles to fill

@@ -62,6 +62,12 @@ CONV_CASES = [
     (2, 7, 9, 96, 24, 1, 1, "none", True, False, False, False),        # linear bottleneck + residual
     (1, 26, 26, 384, 256, 3, 1, "leaky", False, False, False, False),  # tiny-yolo concat conv
     (1, 9, 9, 1024, 512, 1, 1, "leaky", False, False, False, False),   # long K
+    # large 3x3/s1 maps take the halo-staged kernel (csrc/conv3x3_halo.hip)
+    (1, 80, 96, 64, 128, 3, 1, "leaky", True, True, False, False),     # one cin chunk (CK 64), BN 128, residual + pre-add
+    (1, 96, 80, 128, 256, 3, 1, "leaky", True, False, False, False),   # two cin chunks, double-buffered halo, BN 256
+    (1, 112, 80, 32, 64, 3, 1, "leaky", False, False, False, False),   # CK 32, BN 64
+    (2, 94, 100, 96, 64, 3, 1, "none", True, False, False, False),     # partial edge tiles, 3 chunks of 32, batch 2
+    (1, 80, 80, 192, 128, 3, 1, "relu6", False, False, False, False),  # 3 chunks of 64
 ]
 
 
