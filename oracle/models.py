@@ -114,3 +114,11 @@ def tiny_mobile_head_forward(sd, route1, route2, img_size, anchors=TINY_ANCHORS,
     outs = [yolo_decode(h, a, n_class, img_size) for h, a in zip(heads, anchors)]
     io, p = zip(*outs)
     return torch.cat(io, 1), tuple(p)
+
+
+def tiny_mobile_forward(sd, x, anchors=TINY_ANCHORS, n_class=80):
+    """YOLOv3TinyMobile.forward (eval) — yolov3_tiny_mobilenet.py:88-109; encoder: oracle/mobilenet.py
+    (parity unpinned, see its header)."""
+    from .mobilenet import mobilenet_routes
+    route1, route2 = mobilenet_routes(sd, x)
+    return tiny_mobile_head_forward(sd, route1, route2, max(x.shape[-2:]), anchors, n_class)

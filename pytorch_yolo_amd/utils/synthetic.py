@@ -114,14 +114,17 @@ def synth_state_dict(template, seed: int = 1234, n_class: int | None = None):
             if n_class is not None and _is_head(key):
                 _, sh = _head_channel_stats(shape[0], n_class, False)
                 val = (val + sh).astype(np.float32)
-        elif key.endswith(".weight"):  # fused / plain 1-D scale
-            val = rng.uniform(0.5, 1.5, shape).astype(np.float32)
+        elif key.endswith(".weight"):  # 1-D scale of a BN without "batch_norm" in its name (MobileNetV2 keys)
+            val = (rng.uniform(0.5, 1.5, shape) * 0.917).astype(np.float32)
+            if _MBV2_PROJECT_BN.search(key):        # linear-bottleneck BN feeding an identity add
+                val = (val * 0.5).astype(np.float32)
         else:
             val = (rng.standard_normal(shape) * 0.1).astype(np.float32)
         out[key] = torch.from_numpy(val)
     return out
 
 
+_MBV2_PROJECT_BN = re.compile(r"features\.sequence\d+\.\d+\.conv\.[23]\.weight$")
 _RESIDUAL_TAIL = re.compile(r"down\d+\.seq\d+\.1\.")
 
 _HEAD_MARKERS = (

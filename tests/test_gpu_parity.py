@@ -267,6 +267,23 @@ def test_model_small_vs_oracle_and_golden(name):
     _assert_model_close(io_f.cpu(), torch.from_numpy(g["io_fused"]), name + "/fused")
 
 
+def test_mobilenet_variant_vs_oracle():
+    """YOLOv3TinyMobile: depthwise kernels + linear bottlenecks.  The encoder oracle is a restatement of the
+    published MobileNetV2 (torchvision absent: parity unpinned, oracle/mobilenet.py)."""
+    from oracle import models as om
+    from pytorch_yolo_amd import YOLOv3TinyMobile
+    from pytorch_yolo_amd.utils.synthetic import synth_images, synth_state_dict
+    model = YOLOv3TinyMobile(n_class=3).eval()
+    sd = synth_state_dict(model.state_dict(), 5, n_class=3)
+    model.load_state_dict(sd)
+    x = synth_images(2, 96, 128, 3)
+    with torch.no_grad():
+        io_ref, p_ref = om.tiny_mobile_forward(sd, x, om.TINY_ANCHORS, 3)
+        io, p = model.to(DEV)(x.to(DEV))
+    assert io.shape == io_ref.shape == (2, 3 * (6 * 8 + 3 * 4), 8)
+    _assert_model_close(io.cpu(), io_ref, "mobile_96x128", score_max=3e-2, score_rms=4e-3)
+
+
 def test_downsample_sub_is_pre_add():
     from pytorch_yolo_amd.models.yolov3_spp import DownSample
     from pytorch_yolo_amd.utils.synthetic import synth_images, synth_state_dict
