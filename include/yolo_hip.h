@@ -77,6 +77,11 @@ typedef struct YoloConvDesc {
 YOLO_API int yolo_conv2d_fwd(const void* x, const void* w_packed, const float* bias, const void* residual,
                     void* y, void* y_preadd, const YoloConvDesc* d, yolo_stream_t s);
 
+/* First layer fused with the input packing: x is the caller's f32 NCHW batch [n,cin_real,h,w] (cin_real <= 8),
+ * w_packed / bias as for yolo_conv2d_fwd with d->cin = 8; 3x3, stride 1, cout 32, bf16 NHWC output. */
+YOLO_API int yolo_conv1_nchw_f32_fwd(const float* x_nchw, int cin_real, const void* w_packed, const float* bias,
+                                     void* y, const YoloConvDesc* d, yolo_stream_t s);
+
 /* host-side helper (CPU): OIHW f32 [cout,cin_w,k,k] -> packed bf16 (round-to-nearest-even);
  * cin_w <= cin (extra input channels, e.g. the RGB->8 pad, get zero weights). */
 YOLO_API int yolo_pack_conv_weight_f32(const float* w_oihw, int cout, int cin_w, int ksize, int cin,
@@ -119,12 +124,13 @@ YOLO_API int yolo_nms_merge(float* pred, int bs, int rows, int nc, float conf_th
                    int32_t* out_count, int cap, void* workspace, size_t workspace_bytes, yolo_stream_t s);
 
 /* ---- batched launcher: run a recorded list of ops with one FFI crossing (host overhead only). */
-enum { YOLO_OP_CONV = 1, YOLO_OP_MAXPOOL = 2, YOLO_OP_SPP = 3, YOLO_OP_DWCONV = 4 };
+enum { YOLO_OP_CONV = 1, YOLO_OP_MAXPOOL = 2, YOLO_OP_SPP = 3, YOLO_OP_DWCONV = 4, YOLO_OP_CONV1_NCHW = 5 };
 typedef struct YoloOp {
   int32_t kind, _pad;
   const void* x; const void* w; const float* bias; const void* residual; void* y; void* y_aux;
   YoloConvDesc conv;             /* kind CONV; DWCONV/MAXPOOL/SPP reuse the geometry fields
-                                    (ksize/stride/pad, act, views); MAXPOOL dilation = upsample2x field */
+                                    (ksize/stride/pad, act, views); MAXPOOL dilation = upsample2x field;
+                                    CONV1_NCHW: x = f32 NCHW input, res_c_total = real input channels */
 } YoloOp;
 YOLO_API int yolo_run_ops(const YoloOp* ops, int n_ops, yolo_stream_t s);
 

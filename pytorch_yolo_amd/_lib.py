@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libyolo_hip.so")
 
 ACT_NONE, ACT_LEAKY01, ACT_RELU6 = 0, 1, 2
 DT_BF16, DT_F32 = 0, 1
-OP_CONV, OP_MAXPOOL, OP_SPP, OP_DWCONV = 1, 2, 3, 4
+OP_CONV, OP_MAXPOOL, OP_SPP, OP_DWCONV, OP_CONV1_NCHW = 1, 2, 3, 4, 5
 
 
 class YoloConvDesc(C.Structure):
@@ -37,6 +37,8 @@ SIGNATURES = {
     "yolo_abi_version": (C.c_int, []),
     "yolo_pack_input_nchw_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
     "yolo_conv2d_fwd": (C.c_int, [C.c_void_p] * 6 + [C.POINTER(YoloConvDesc), C.c_void_p]),
+    "yolo_conv1_nchw_f32_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.POINTER(YoloConvDesc), C.c_void_p]),
     "yolo_pack_conv_weight_f32": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
     "yolo_dwconv3x3_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 12 + [C.c_void_p]),
     "yolo_maxpool_fwd": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 14 + [C.c_void_p]),

@@ -117,6 +117,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv3x3_halo_kernel(co
   issue_halo(0, 0, 0, HPT);
   issue_w(0, 0, 0);
 
+  auto pix_of = [&](int row) -> long {
+    const int q = wm * TM + row;
+    const int yy = y0 + q / TW, xx = x0 + q % TW;
+    return (yy < d.h && xx < d.w) ? ((long)(b * d.h + yy) * d.w + xx) : -1L;
+  };
+  ResPrefetch<MI, TM> rpre;
+  const bool pre_res = a.res != nullptr && !(a.debug & 128);
+
   int wb = 0;
   for (int c = 0; c < n_chunks; ++c) {
     const char* const hbuf = s_halo + (HB == 2 ? (c & 1) : 0) * HALO_B;
@@ -125,6 +133,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv3x3_halo_kernel(co
     for (int tap = 0; tap < 9; ++tap) {
       wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();       // stage (c,tap) is in LDS; every wave finished reading stage (c,tap)-1
+      // residual tile -> registers two taps before the end: it lands under the MFMAs of taps 6..7
+      if (pre_res && c == n_chunks - 1 && tap == 6) prefetch_residual<MI, TM>(a, rpre, lane, n0 + wn * TN, pix_of);
       // prefetch: weights of the next step, and 1/9 of the next chunk's halo (HB == 2)
       if (tap < 8) {
         issue_w(wb ^ 1, c, tap + 1);
@@ -186,6 +196,125 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv3x3_halo_kernel(co
   });
 }
 
+// ---------------------------------------------------------------------------------------------------
+// First layer, fused with the input packing: x is the caller's float32 NCHW image batch (c <= 8 channels,
+// reference input contract utils/dataset_csv.py:79-87), y = act(conv3x3/s1(x) + bias) in bf16 NHWC, cout = 32.
+// One block = one 16x16 output tile: the 18x18 halo is read from the c planes, rounded to bf16 and laid out
+// NHWC8 in LDS (16 B per pixel); K = 10 taps x 8 channels (tap 9 and channels >= c carry zero weights), i.e.
+// five 32x32x16 MFMAs per 32 pixels with the weight fragments held in registers.  The layer is HBM-bound
+// (write 64 B per pixel); the implicit-GEMM kernel spent its time issuing nine 16-byte gathers per pixel.
+constexpr int kConv1TilesPerBlock = 5;
+
+__global__ __launch_bounds__(256) void conv1_nchw_kernel(const ConvArgs a, const float* __restrict__ x_nchw, int cin_real) {
+  constexpr int HW2 = 18, HP = 18 * 18, TM = 64;
+  constexpr int SP = 80;                                      // bf16 staging pitch: 32 couts (64 B) + 16 B pad
+  constexpr int HALO_B = ((HP * 16 + 1023) / 1024) * 1024;    // 6 KB
+  constexpr int LDS_B = 2 * HALO_B + 4 * TM * SP;             // 32.5 KB
+  constexpr int TPB = kConv1TilesPerBlock;
+  __shared__ __attribute__((aligned(16))) char smem[LDS_B];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const YoloConvDesc& d = a.d;
+  const int tiles_x = (d.w + 15) / 16, tiles_y = (d.h + 15) / 16;
+  const int groups_x = (tiles_x + TPB - 1) / TPB;
+  int swz = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tx0 = (swz % groups_x) * TPB;
+  swz /= groups_x;
+  const int y0 = (swz % tiles_y) * 16;
+  const int b = swz / tiles_y;
+  const int n_t = min(TPB, tiles_x - tx0);
+
+  // weight fragments (A operand): lane = cout r32, k = ks*16 + khalf*8 + 0..7 of the packed [cout_pad][kpad] matrix
+  const int r32 = lane & 31, khalf = lane >> 5;
+  bf16x8 wf[5];
+#pragma unroll
+  for (int ks = 0; ks < 5; ++ks) wf[ks] = *reinterpret_cast<const bf16x8*>(a.w + (long)r32 * d.kpad + ks * 16 + khalf * 8);
+  f32x4 bias4[4];
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) bias4[g4] = *reinterpret_cast<const f32x4*>(a.bias + g4 * 8 + khalf * 4);
+
+  // halo pixels owned by this thread (2 of the 324), prefetched one tile ahead into registers
+  const long plane = (long)d.h * d.w;
+  const int hp0 = tid, hp1 = tid + 256;
+  const int hy0 = hp0 / HW2, hx0 = hp0 - hy0 * HW2, hy1 = hp1 / HW2, hx1 = hp1 - hy1 * HW2;
+  float pre[2][8];
+  auto fetch = [&](int t) {
+    const int x0 = (tx0 + t) * 16;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int hy = u ? hy1 : hy0, hx = u ? hx1 : hx0;
+      const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+      const bool ok = (u == 0 || hp1 < HP) && (unsigned)yy < (unsigned)d.h && (unsigned)xx < (unsigned)d.w;
+      const float* src = x_nchw + ((long)b * cin_real) * plane + (long)yy * d.w + xx;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pre[u][e] = (ok && e < cin_real) ? src[e * plane] : 0.f;
+    }
+  };
+  auto commit = [&](int hb) {                                  // registers -> LDS halo buffer as NHWC8 bf16
+    char* const hbuf = smem + hb * HALO_B;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (u == 1 && hp1 >= HP) continue;
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (bf16_t)pre[u][e];
+      *reinterpret_cast<bf16x8*>(hbuf + (u ? hp1 : hp0) * 16) = v;
+    }
+  };
+
+  char* const stg = smem + 2 * HALO_B + wave * (TM * SP);
+  fetch(0);
+  for (int t = 0; t < n_t; ++t) {
+    commit(t & 1);
+    __syncthreads();                       // halo t visible; (also: everyone is past the reads of halo t-2's buffer)
+    if (t + 1 < n_t) fetch(t + 1);         // global loads fly during the MFMAs and the stores below
+    const char* const hbuf = smem + (t & 1) * HALO_B;
+    const int x0 = (tx0 + t) * 16;
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+      int tap = ks * 2 + khalf;
+      if (tap > 8) tap = 8;                                   // tap 9 has zero weights: read any valid pixel
+      const int dh = (tap * 11) >> 5, dw = tap - 3 * dh;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int q = wave * TM + j * 32 + r32;
+        const int hr = ((q >> 4) + dh) * HW2 + (q & 15) + dw;
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(hbuf + hr * 16);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf, acc[j], 0, 0, 0);
+      }
+    }
+    // epilogue: no residual / pre-add copy here, so the tile is rounded to bf16 before staging (single rounding);
+    // lane = pixel, registers = couts -> LDS [pixel][32 couts] -> 16 B per lane, 1 KiB contiguous per instruction
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)apply_act(acc[j][g4 * 4 + e] + bias4[g4][e], d.act);
+        *reinterpret_cast<bf16x4*>(stg + (j * 32 + r32) * SP + (g4 * 8 + khalf * 4) * 2) = o;
+      }
+    __builtin_amdgcn_wave_barrier();
+    bf16_t* const ybase = reinterpret_cast<bf16_t*>(a.y) + d.out_c_offset + (lane & 3) * 8;
+#pragma unroll
+    for (int pass = 0; pass < TM / 16; ++pass) {
+      const int row = pass * 16 + (lane >> 2);
+      const int q = wave * TM + row;
+      const int yy = y0 + (q >> 4), xx = x0 + (q & 15);
+      if (yy < d.h && xx < d.w) {
+        const u32x4 val = *reinterpret_cast<const u32x4*>(stg + row * SP + (lane & 3) * 16);
+        *reinterpret_cast<u32x4*>(ybase + ((long)(b * d.h + yy) * d.w + xx) * d.out_c_total) = val;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 template <int TH, int TW, int BN, int WAVES_M, int WAVES_N, int CK, int HB>
 int launch(const ConvArgs& a, hipStream_t s) {
   ConvArgs b = a;
@@ -216,4 +345,18 @@ int yolo_conv::launch_halo3x3(const ConvArgs& a, hipStream_t s) {
   const bool one = d.cin == 32;
   if (d.cout % 128 == 0) return one ? launch<16, 16, 128, 4, 2, 32, 1>(a, s) : launch<16, 16, 128, 4, 2, 32, 2>(a, s);
   return one ? launch<16, 16, 64, 4, 1, 32, 1>(a, s) : launch<16, 16, 64, 4, 1, 32, 2>(a, s);
+}
+
+
+// float32 NCHW input -> first conv layer (see conv1_nchw_kernel).  Returns 1 if the shape is not covered.
+int yolo_conv::launch_conv1_nchw(const ConvArgs& a, const float* x_nchw, int cin_real, hipStream_t s) {
+  const YoloConvDesc& d = a.d;
+  if (d.ksize != 3 || d.stride != 1 || d.pad != 1 || d.cin != 8 || cin_real > 8 || d.cout != 32 || d.upsample2x ||
+      d.out_dtype != YOLO_DT_BF16 || d.kpad < 80 || a.res || a.aux)
+    return 1;
+  const int tiles_x = (d.w + 15) / 16;
+  const long grid = (long)d.n * ((d.h + 15) / 16) * ((tiles_x + kConv1TilesPerBlock - 1) / kConv1TilesPerBlock);
+  if (grid > 0x7fffffffL) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv1 grid too large");
+  hipLaunchKernelGGL(conv1_nchw_kernel, dim3((unsigned)grid), dim3(256), 0, s, a, x_nchw, cin_real);
+  return yolo_check_launch("yolo_conv1_nchw_f32_fwd");
 }

@@ -54,9 +54,33 @@ __device__ __forceinline__ void lds_dma16s(__amdgpu_buffer_rsrc_t rsrc, char* ld
 // the output pixel index (n*ho*wo order) or -1.  `stg` = private per-wave LDS slab of TM*kEpiPitch bytes.
 constexpr int kEpiPitch = 144;   // 32 f32 + 16 B pad
 
+// Residual tile prefetched into registers during the last K steps (same lane mapping as the coalesced phase),
+// so the read overlaps the MFMAs instead of extending the epilogue.
+template <int MI, int TM>
+struct ResPrefetch {
+  bf16x8 v[MI][TM / 16];
+};
+
+template <int MI, int TM, typename PixOf>
+__device__ __forceinline__ void prefetch_residual(const ConvArgs& a, ResPrefetch<MI, TM>& r, int lane, int cout0,
+                                                  PixOf pix_of) {
+  const YoloConvDesc& d = a.d;
+  const int crow = lane >> 2, cchunk = lane & 3;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int cbase = cout0 + i * 32;
+#pragma unroll
+    for (int pass = 0; pass < TM / 16; ++pass) {
+      const long pix = pix_of(pass * 16 + crow);
+      if (pix >= 0 && cbase < d.cout)
+        r.v[i][pass] = *reinterpret_cast<const bf16x8*>(a.res + pix * d.res_c_total + d.res_c_offset + cbase + cchunk * 8);
+    }
+  }
+}
+
 template <int MI, int NI, int TM, typename PixOf>
 __device__ __forceinline__ void epilogue_lds(const ConvArgs& a, const f32x16 (&acc)[MI][NI], char* stg, int lane,
-                                             int cout0, PixOf pix_of) {
+                                             int cout0, PixOf pix_of, const ResPrefetch<MI, TM>* rpre = nullptr) {
   const YoloConvDesc& d = a.d;
   const int r32 = lane & 31, khalf = lane >> 5;
   const int crow = lane >> 2, cchunk = lane & 3;   // coalesced phase: 16 pixel rows x 4 chunks of 8 couts
@@ -94,7 +118,8 @@ __device__ __forceinline__ void epilogue_lds(const ConvArgs& a, const f32x16 (&a
           *reinterpret_cast<bf16x8*>(a.aux + pix * d.aux_c_total + d.aux_c_offset + cofs) = o;
         }
         if (a.res) {
-          const bf16x8 rv = *reinterpret_cast<const bf16x8*>(a.res + pix * d.res_c_total + d.res_c_offset + cofs);
+          const bf16x8 rv = rpre ? rpre->v[i][pass]
+                                 : *reinterpret_cast<const bf16x8*>(a.res + pix * d.res_c_total + d.res_c_offset + cofs);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
         }
@@ -126,5 +151,6 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nblk) {
 }
 
 int launch_halo3x3(const ConvArgs& a, hipStream_t s);   // conv3x3_halo.hip; returns 1 if it does not apply
+int launch_conv1_nchw(const ConvArgs& a, const float* x_nchw, int cin_real, hipStream_t s);
 
 }  // namespace yolo_conv

@@ -50,7 +50,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel
   static_assert(TM % 32 == 0 && TN % 32 == 0 && PIT >= 1 && WIT >= 1, "tile");
   static_assert(NS * STAGE_B <= 160 * 1024, "LDS");
 
-  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE_B];   // per stage: [BNL weight rows][BM pixel rows]
+  constexpr int RING_B = NS * STAGE_B;
+  constexpr int LDS_B = (LDS_EPI && NW * TM * kEpiPitch > RING_B) ? NW * TM * kEpiPitch : RING_B;   // epilogue slab reuses the ring
+  __shared__ __attribute__((aligned(16))) char smem[LDS_B];   // per stage: [BNL weight rows][BM pixel rows]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -200,6 +202,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel
       stage_end();
     }
 
+  auto pix_of = [&](int row) -> long {
+    const int pix = m0 + wm * TM + row;
+    return pix < a.M ? (long)pix : -1L;
+  };
+
   int buf = 0;
   for (int s = 0; s < steps; ++s) {
     // stage s must have landed: allow the younger stages (up to NS-2 of them) to stay in flight
@@ -258,12 +265,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel
   // ---- epilogue: lane = pixel (col), registers = couts (row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) ----
   const bool f32_out = d.out_dtype == YOLO_DT_F32;
   if constexpr (LDS_EPI) {
-    static_assert(NW * TM * kEpiPitch <= NS * STAGE_B, "staging fits the ring");
     __syncthreads();                                 // every wave is done with the last stage: LDS is free
-    epilogue_lds<MI, NI, TM>(a, acc, smem + wave * (TM * kEpiPitch), lane, n0 + wn * TN, [&](int row) -> long {
-      const int pix = m0 + wm * TM + row;
-      return pix < a.M ? (long)pix : -1L;
-    });
+    epilogue_lds<MI, NI, TM>(a, acc, smem + wave * (TM * kEpiPitch), lane, n0 + wn * TN, pix_of);
   } else {
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
@@ -418,13 +421,46 @@ int yolo_conv2d_launch(const void* x, const void* w, const float* bias, const vo
   if (conv_variant_override < 0) {
     const long tiles256 = ((M + 255) / 256) * (d.cout / 256);
     pick = (d.cout % 256 == 0 && tiles256 >= 160) ? 5 : 0;
+    // short-K 1x1 layers on big maps are latency/HBM-bound: 256x128 tiles with 32-deep stages keep
+    // 16 waves per CU resident (two 8-wave blocks), which hides the per-tile prologue/epilogue
+    if (d.ksize == 1 && d.cin <= 512 && M >= 40000) pick = 9;
   }
   switch (pick) {
     case 3: return YOLO_CFG(256, 128, 4, 2, 64, 2, true);
+    case 7: return YOLO_CFG(128, 128, 2, 2, 32, 2, true);
+    case 8: return YOLO_CFG(128, 64, 2, 2, 64, 2, true);
+    case 9: return YOLO_CFG(256, 128, 4, 2, 32, 2, true);
     case 5: return YOLO_CFG(256, 256, 4, 2, 64, 2, true);
     default: return YOLO_CFG(128, 128, 2, 2, 64, 2, true);
   }
 #undef YOLO_CFG
+}
+
+// First layer straight from the caller's float32 NCHW batch (fuses yolo_pack_input_nchw_f32 + conv).
+extern "C" int yolo_conv1_nchw_f32_fwd(const float* x_nchw, int cin_real, const void* w_packed, const float* bias, void* y,
+                                       const YoloConvDesc* dp, yolo_stream_t s) {
+  YOLO_REQUIRE(x_nchw && w_packed && bias && y && dp, "conv1: null pointer");
+  const YoloConvDesc& d = *dp;
+  YOLO_REQUIRE(cin_real >= 1 && cin_real <= 8 && d.cin == 8, "conv1: 1..8 input channels (packed K uses cin = 8)");
+  YOLO_REQUIRE(d.out_c_offset % 8 == 0 && d.out_c_total % 8 == 0 && d.out_c_offset + d.cout <= d.out_c_total, "conv1: bad output view");
+  YOLO_REQUIRE(d.ho == d.h && d.wo == d.w, "conv1: 3x3 / stride 1 / pad 1 only");
+  ConvArgs a;
+  a.x = nullptr;
+  a.w = (const bf16_t*)w_packed;
+  a.bias = bias;
+  a.res = nullptr;
+  a.y = y;
+  a.aux = nullptr;
+  a.d = d;
+  a.M = d.n * d.ho * d.wo;
+  a.n_tiles = 1;
+  a.steps = 0;
+  a.x_bytes = 0;
+  a.w_bytes = 0;
+  a.debug = 0;
+  const int rc = launch_conv1_nchw(a, x_nchw, cin_real, (hipStream_t)s);
+  if (rc == 1) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv1: shape not covered (3x3 s1, cout 32, bf16 out)");
+  return rc;
 }
 
 extern "C" int yolo_conv2d_fwd(const void* x, const void* w_packed, const float* bias, const void* residual, void* y,

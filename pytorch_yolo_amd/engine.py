@@ -26,7 +26,7 @@ from typing import List, Optional
 import torch
 
 from . import kernels as K
-from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU6, DT_BF16, DT_F32, OP_CONV, OP_DWCONV,
+from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU6, DT_BF16, DT_F32, OP_CONV, OP_CONV1_NCHW, OP_DWCONV,
                    OP_MAXPOOL, OP_SPP, YoloOp)
 
 
@@ -156,6 +156,7 @@ class Plan:
         self._bufs: List[Buf] = []
         self._keep = []                 # packed weights / biases kept alive
         self._place()
+        self.fused_input = self._first_conv_reads_nchw()
         self._alloc()
         self._build_ops()
         self._graph = None
@@ -221,6 +222,22 @@ class Plan:
                 res, y = nd.srcs[1], nd.outs[0]
                 y.buf, y.c_offset = res.buf, res.c_offset
 
+    def _first_conv_reads_nchw(self) -> bool:
+        """The first layer can read the caller's float32 NCHW batch itself (yolo_conv1_nchw_f32_fwd): then the
+        NHWC bf16 copy of the input is never materialised."""
+        x = self.rec.input
+        if len(x.consumers) != 1 or x.consumers[0].kind != "conv" or self.rec.c_in > 8:
+            return False
+        nd = x.consumers[0]
+        w, _ = nd.attrs["weight"]
+        y = nd.outs[0]
+        ok = (w.shape[0] == 32 and w.shape[2] == 3 and nd.attrs["stride"] == 1 and not nd.attrs["has_res"]
+              and len(nd.outs) == 1 and "up_into" not in nd.attrs and not y.f32 and y.buf is not None
+              and y.c_offset % 8 == 0)
+        if ok and x.buf in self._bufs:
+            self._bufs.remove(x.buf)          # no packed input buffer needed
+        return ok
+
     def _alloc(self):
         for b in self._bufs:
             dt = torch.float32 if b.f32 else torch.bfloat16
@@ -256,8 +273,12 @@ class Plan:
                                 res=(res.buf.c_total, res.c_offset) if res is not None else (0, 0),
                                 aux=(aux.buf.c_total, aux.c_offset) if aux is not None else (0, 0))
                 op = YoloOp()
-                op.kind = OP_CONV
-                op.x, op.w, op.bias = x.buf.tensor.data_ptr(), wp.data_ptr(), bp.data_ptr()
+                fused_first = self.fused_input and x is self.rec.input
+                op.kind = OP_CONV1_NCHW if fused_first else OP_CONV
+                if fused_first:
+                    d.res_c_total = self.rec.c_in          # real input channels (x pointer is patched per call)
+                op.x = None if fused_first else x.buf.tensor.data_ptr()
+                op.w, op.bias = wp.data_ptr(), bp.data_ptr()
                 op.residual = res.buf.tensor.data_ptr() if res is not None else None
                 op.y = dst.buf.tensor.data_ptr()
                 op.y_aux = aux.buf.tensor.data_ptr() if aux is not None else None
@@ -312,10 +333,20 @@ class Plan:
     def input_buffer(self) -> torch.Tensor:
         return self.rec.input.buf.tensor
 
+    def feed(self, x: torch.Tensor):
+        """Hand the float32 NCHW batch to the layer list: either the first conv reads it directly
+        (pointer patched into its op) or it is packed to NHWC bf16 first."""
+        if self.fused_input:
+            if x.dtype != torch.float32 or not x.is_contiguous() or tuple(x.shape[1:]) != (self.rec.c_in, self.rec.input.h, self.rec.input.w):
+                raise RuntimeError("input must be contiguous float32 NCHW of the planned shape")
+            self.op_array[0].x = x.data_ptr()
+        else:
+            K.pack_input(x, self.input_buffer)
+
     def _launch(self, x: torch.Tensor, io: torch.Tensor, ps, timing=None):
         """pack -> layer list -> decodes on the current stream.  ``timing`` = (start, end) torch events
         recorded around the layer list (bench.py's roofline measurement)."""
-        K.pack_input(x, self.input_buffer)
+        self.feed(x)
         if timing is not None:
             timing[0].record()
         K.run_ops(self.op_array, self.n_ops)
@@ -332,7 +363,7 @@ class Plan:
         for i in range(self.n_ops):
             op = self.op_array[i]
             d = op.conv
-            if op.kind == OP_CONV:
+            if op.kind in (OP_CONV, OP_CONV1_NCHW):
                 cin = self.rec.c_in if first else d.cin      # the first layer's 3 -> 8 channel pad is not work
                 first = False
                 total += 2.0 * d.n * d.ho * d.wo * d.cout * d.ksize * d.ksize * cin
@@ -414,7 +445,7 @@ class StreamedPlan:
             lo, hi = i * self.sub, (i + 1) * self.sub
             st.wait_stream(cur)
             with torch.cuda.stream(st):
-                K.pack_input(x[lo:hi], pl.input_buffer)
+                pl.feed(x[lo:hi])
                 K.run_ops(pl.op_array, pl.n_ops)
                 self._marks[i].record(st)
                 for hd, p in zip(pl.heads, ps):
@@ -458,7 +489,7 @@ def run_standalone(trace_fn, x: torch.Tensor):
     rec = Recorder(bs, c, h, w)
     out = trace_fn(rec, rec.input)
     plan = Plan(rec, x.device, n_class=0, img_size=max(h, w))
-    K.pack_input(x, plan.input_buffer)
+    plan.feed(x)
     K.run_ops(plan.op_array, plan.n_ops)
     if isinstance(out, (tuple, list)):
         return tuple(_sym_to_nchw(s) for s in out)

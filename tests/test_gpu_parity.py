@@ -119,6 +119,26 @@ def test_conv_kernel(case):
         assert torch.all(aux[..., :8] == -77.0)
 
 
+@pytest.mark.parametrize("cin,h,w", [(3, 37, 50), (3, 64, 64), (1, 20, 33), (8, 16, 16)])
+def test_first_layer_fused_with_input_packing(cin, h, w):
+    """yolo_conv1_nchw_f32_fwd: the first ConvBlock reads the float32 NCHW batch directly (no packed copy)."""
+    from oracle.blocks import conv_bn_leaky
+    from pytorch_yolo_amd import engine
+    from pytorch_yolo_amd.models.yolo_base import ConvBlock
+    from pytorch_yolo_amd.utils.synthetic import synth_images, synth_state_dict
+    blk = ConvBlock(cin, 32, size=3, stride=1).eval()
+    blk.load_state_dict(synth_state_dict(blk.state_dict(), 9))
+    x = synth_images(2, h, w, 4, channels=cin)
+    rec = engine.Recorder(2, cin, h, w)
+    blk._trace(rec, rec.input)
+    assert engine.Plan(rec, torch.device(DEV), 0, max(h, w)).fused_input
+    got = blk(x.to(DEV)).cpu()
+    sd = {"b." + k: v for k, v in blk.state_dict().items()}
+    want = conv_bn_leaky({k: v for k, v in sd.items()}, "b", _bf16r(x))
+    # weights are bf16-rounded after BN folding in the product: compare at bf16 resolution
+    torch.testing.assert_close(got, want, rtol=2e-2, atol=2e-2)
+
+
 @pytest.mark.parametrize("k,s", [(2, 2), (2, 1), (5, 1), (9, 1), (13, 1), (3, 2)])
 def test_maxpool_exact(k, s):
     from pytorch_yolo_amd.models.yolo_base import MaxPool

@@ -13,7 +13,7 @@ import torch
 import _cases as C
 from pytorch_yolo_amd import YOLOv3SPP, YOLOv3Tiny, YOLOv3TinyMobile, _lib, engine
 from pytorch_yolo_amd import kernels as K
-from pytorch_yolo_amd._lib import OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_SPP
+from pytorch_yolo_amd._lib import OP_CONV, OP_CONV1_NCHW, OP_DWCONV, OP_MAXPOOL, OP_SPP
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -102,7 +102,8 @@ def test_planner_spp_fusions():
     plan = _dry_plan(YOLOv3SPP(anchors=C.SPP_ANCHORS).eval(), 640)
     ops = _ops(plan)
     kinds = [o.kind for o in ops]
-    assert kinds.count(OP_CONV) == 76 and kinds.count(OP_SPP) == 1 and len(ops) == 77      # no add / cat / upsample launches
+    assert ops[0].kind == OP_CONV1_NCHW and plan.fused_input                              # first layer reads the NCHW f32 batch itself
+    assert kinds.count(OP_CONV) == 75 and kinds.count(OP_SPP) == 1 and len(ops) == 77      # no add / cat / upsample / pack launches
     convs = [o for o in ops if o.kind == OP_CONV]
     assert sum(1 for o in convs if o.residual) == 23                                        # every Add is an epilogue
     assert all(o.residual == o.y for o in convs if o.residual)                              # ... written in place
@@ -130,7 +131,7 @@ def test_planner_tiny_and_mobile():
     assert plan.rows_total == 2535 and [h["stride"] for h in plan.heads] == [16.0, 32.0]
     plan = _dry_plan(YOLOv3TinyMobile().eval(), 416)
     kinds = [o.kind for o in _ops(plan)]
-    assert kinds.count(OP_DWCONV) == 17 and kinds.count(OP_CONV) == 40
+    assert kinds.count(OP_DWCONV) == 17 and kinds.count(OP_CONV) == 40 and not plan.fused_input   # stride-2 stem: generic path
     assert sum(1 for o in _ops(plan) if o.kind == OP_CONV and o.residual) == 10          # MobileNetV2 identity shortcuts
 
 

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Does splitting the batch over S concurrent HIP streams hide the tile-quantisation tail?  (experiment)"""
+"""Experiment: sub-batches small enough that consecutive layers hand activations over through the 256 MB
+Infinity Cache.  S streams, each running C chunks back to back (layer list per chunk)."""
 import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,19 +17,20 @@ model = wl["cls"](**wl["kw"]).eval()
 model.load_state_dict(synth_state_dict(model.state_dict(), 1234, n_class=80))
 model = model.to(dev)
 x = synth_images(32, 640, 640, 0).to(dev)
-for S in (1, 2, 4):
-    sub = 32 // S
-    plans, xs = [], []
-    for i in range(S):
+for S, sub in ((1, 32), (2, 16), (2, 8), (2, 4), (4, 8), (1, 8), (1, 4)):
+    plans = []
+    for i in range(S):                       # one plan (buffer set) per stream, reused by its chunks
         rec = engine.Recorder(sub, 3, 640, 640); model._trace(rec, rec.input)
-        plans.append(engine.Plan(rec, dev, 80, 640)); xs.append(x[i * sub:(i + 1) * sub].contiguous())
+        plans.append(engine.Plan(rec, dev, 80, 640))
     streams = [torch.cuda.Stream() for _ in range(S)]
+    n_chunks = 32 // sub
     def step():
         cur = torch.cuda.current_stream()
         for s in streams: s.wait_stream(cur)
-        for i, s in enumerate(streams):
-            with torch.cuda.stream(s):
-                plans[i].feed(xs[i])
+        for ci in range(n_chunks):
+            i = ci % S
+            with torch.cuda.stream(streams[i]):
+                plans[i].feed(x[ci * sub:(ci + 1) * sub])
                 K.run_ops(plans[i].op_array, plans[i].n_ops)
         for s in streams: cur.wait_stream(s)
     for _ in range(3): step()
@@ -36,4 +38,6 @@ for S in (1, 2, 4):
     t0 = time.perf_counter()
     for _ in range(10): step()
     torch.cuda.synchronize()
-    print(f"streams {S}: {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms per 32 images (pack + conv layers)", flush=True)
+    print(f"streams {S} x sub-batch {sub}: {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms per 32 images", flush=True)
+    del plans
+    torch.cuda.empty_cache()

@@ -19,7 +19,7 @@ spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench
 bench = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(bench)
 from pytorch_yolo_amd import kernels as K
-from pytorch_yolo_amd._lib import OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_SPP, YoloOp
+from pytorch_yolo_amd._lib import OP_CONV, OP_CONV1_NCHW, OP_DWCONV, OP_MAXPOOL, OP_SPP, YoloOp
 from pytorch_yolo_amd.utils.synthetic import synth_images, synth_state_dict
 
 
@@ -38,7 +38,7 @@ def main():
     model.n_streams = 1
     x = synth_images(bs, wl["hw"], wl["hw"], 0).to(dev)
     plan = model.plan_for(x)
-    K.pack_input(x, plan.input_buffer)
+    plan.feed(x)
     K.run_ops(plan.op_array, plan.n_ops)
     torch.cuda.synchronize()
     times = [[] for _ in range(plan.n_ops)]
@@ -58,7 +58,7 @@ def main():
         d = op.conv
         ms = statistics.median(times[i])
         tot_ms += ms
-        if op.kind == OP_CONV:
+        if op.kind in (OP_CONV, OP_CONV1_NCHW):
             M, N, Kd = d.n * d.ho * d.wo, d.cout, d.ksize * d.ksize * d.cin
             fl = 2.0 * M * N * Kd
             by = d.n * d.h * d.w * d.cin * 2 + M * N * (4 if d.out_dtype else 2) * (4 if d.upsample2x else 1) + N * Kd * 2
