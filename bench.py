@@ -61,7 +61,7 @@ def host_cores() -> int:
     return max(1, min(n, 16))
 
 
-def cpu_baseline(workload: str, seconds_budget: float = 25.0):
+def cpu_baseline(workload: str, seconds_budget: float = 20.0):
     """The oracle (CPU restatement of the reference path) timed on this box's host cores."""
     import numpy as np
     from oracle import models as om
@@ -85,7 +85,7 @@ def cpu_baseline(workload: str, seconds_budget: float = 25.0):
             io, _ = fwd(sd, x, anchors, 80)
             onms.non_max_suppression(io.numpy(), CONF_THRES, NMS_THRES)
             iters += 1
-            if time.time() - t0 > seconds_budget or iters >= 3:
+            if time.time() - t0 > seconds_budget or (iters >= 3 and time.time() - t0 > 10.0):
                 break
     dt = time.time() - t0
     return dict(value=round(bs * iters / dt, 3), unit="images/s", cores=cores, kind="port",
@@ -131,14 +131,18 @@ def main():
     io, ps = plan.new_outputs()
     flops_step = plan.conv_flops()
 
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * (args.steps + args.warmup))]
-    conv_ms = []
+    n_streams = plan.n_streams
+    total_steps = args.steps + args.warmup
+    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_streams)]
+          for _ in range(total_steps)]
+    ref = torch.cuda.Event(enable_timing=True)
+    free_run = world == 1          # no per-step join: the S sub-batch pipelines run freely until the final sync
 
     def step(i):
-        """pack -> 76 conv launches (+pools) -> 3 decodes -> NMS (-> all-gather). HIP events bracket the
-        conv launch list on the stream it is launched on (torch's current stream)."""
-        plan._launch(x, io, ps, timing=(ev[2 * i], ev[2 * i + 1]))
-        nms_raw(io, CONF_THRES, NMS_THRES, out=nms_out)
+        """Per stream: conv1 (reads the NCHW batch) -> 75 conv launches + SPP -> 3 decodes -> NMS on its sub-batch
+        (-> join + all-gather when sharded over ranks).  HIP events bracket every stream's conv launch list on
+        the stream it is launched on."""
+        plan.launch_detect(x, io, ps, nms_out, CONF_THRES, NMS_THRES, timing=ev[i], join=not free_run)
         if world > 1:
             return gather_detections(nms_out[0], nms_out[2])
         return nms_out[0], nms_out[2]
@@ -153,13 +157,18 @@ def main():
         for i in range(args.warmup):
             step(i)
         sync_all()
+        ref.record()
         t0 = time.perf_counter()
-        for i in range(args.warmup, args.warmup + args.steps):
+        for i in range(args.warmup, total_steps):
             dets, counts = step(i)
         sync_all()
         dt = time.perf_counter() - t0
-    for i in range(args.warmup, args.warmup + args.steps):
-        conv_ms.append(ev[2 * i].elapsed_time(ev[2 * i + 1]))
+    # conv time of a step = union over the streams of their conv-list intervals (never over-states the rate)
+    conv_ms = []
+    for i in range(args.warmup, total_steps):
+        starts = [ref.elapsed_time(e0) for e0, _ in ev[i]]
+        ends = [ref.elapsed_time(e1) for _, e1 in ev[i]]
+        conv_ms.append(max(ends) - min(starts))
     n_dets = counts.cpu().tolist()
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -188,10 +197,10 @@ def main():
                        "n_class": nc, "conf_thres": CONF_THRES, "nms_thres": NMS_THRES,
                        "sharding": f"batch x{world}" + (" + RCCL all-gather of detections" if world > 1 else ""),
                        "mean_detections_per_image": round(sum(n_dets) / max(1, len(n_dets)), 1),
-                       "streams_per_gpu": getattr(plan, "streams", None) and len(plan.streams) or 1},
+                       "streams_per_gpu": n_streams},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                         "kernel": "conv_igemm_bf16_kernel (all conv launches of one forward)",
+                         "kernel": "conv kernels of one forward (conv_igemm_bf16 / conv3x3_halo / conv1_nchw), union over the streams",
                          "flops_per_step": flops_step, "ms_per_step_conv": round(conv_ms_avg, 4)},
         }
         if not args.no_cpu_baseline and world == 1:

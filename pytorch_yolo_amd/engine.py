@@ -356,6 +356,16 @@ class Plan:
             s = hd["sym"]
             K.decode(s.buf.tensor, hd["anchors"], self.n_class, hd["stride"], io, hd["row"], p)
 
+    def launch_detect(self, x, io, ps, nms_out, conf_thres, nms_thres, timing=None, join=True):
+        """forward + decode + MERGE-NMS into caller-provided buffers; no host sync.
+        nms_out = (dets [bs,cap,7] f32, idx [bs,cap] i32, count [bs] i32).  ``timing``: one (start, end)
+        event pair per stream, recorded around the conv launch list."""
+        from .utils.utils import nms_launch
+        self._launch(x, io, ps, timing=timing[0] if timing else None)
+        nms_launch(io, conf_thres, nms_thres, nms_out, slot=0)
+
+    n_streams = 1
+
     def conv_flops(self) -> float:
         """Exact algorithmic FLOPs of the recorded conv launches (2*M*Cout*K with logical sizes)."""
         total = 0.0
@@ -461,6 +471,28 @@ class StreamedPlan:
         io, ps = self.new_outputs()
         self._launch(x, io, ps)
         return io, ps
+
+    @property
+    def n_streams(self):
+        return len(self.streams)
+
+    def launch_detect(self, x, io, ps, nms_out, conf_thres, nms_thres, timing=None, join=True):
+        """Each stream runs the WHOLE pipeline (pack/conv1 -> layers -> decode -> NMS) of its sub-batch into
+        slices of the shared buffers.  With ``join=False`` the calling stream neither waits for the previous
+        work nor for this one: successive calls then form S free-running pipelines (in-order per stream, so
+        buffer reuse is safe) — the caller synchronises before reading results."""
+        from .utils.utils import nms_launch
+        cur = torch.cuda.current_stream()
+        for i, (pl, st) in enumerate(zip(self.subs, self.streams)):
+            lo, hi = i * self.sub, (i + 1) * self.sub
+            if join:
+                st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                pl._launch(x[lo:hi], io[lo:hi], tuple(p[lo:hi] for p in ps), timing=timing[i] if timing else None)
+                nms_launch(io[lo:hi], conf_thres, nms_thres, tuple(t[lo:hi] for t in nms_out), slot=i)
+        if join:
+            for st in self.streams:
+                cur.wait_stream(st)
 
     run_graph = None   # bound below (shares Plan.run_graph's capture logic)
 

@@ -185,6 +185,15 @@ class YOLOBase(nn.Module):
     def detect(self, x, conf_thres=0.5, nms_thres=0.5):
         """The composition inside reference test_model (utils/utils.py:374-378):
         ``non_max_suppression(model(x)[0], conf_thres, nms_thres)``."""
-        from ..utils.utils import non_max_suppression
-        io, _ = self.forward(x)
-        return non_max_suppression(io, conf_thres, nms_thres)
+        from ..utils.utils import nms_capacity, split_detections
+        if self.training:
+            raise NotImplementedError("detect() is an inference call: .eval() first")
+        x = x.float().contiguous()
+        plan = self.plan_for(x)
+        io, ps = plan.new_outputs()
+        bs, cap = x.shape[0], nms_capacity(plan.rows_total, self.n_class)
+        out = (torch.empty((bs, cap, 7), dtype=torch.float32, device=x.device),
+               torch.empty((bs, cap), dtype=torch.int32, device=x.device),
+               torch.empty((bs,), dtype=torch.int32, device=x.device))
+        plan.launch_detect(x, io, ps, out, conf_thres, nms_thres)
+        return split_detections(*out)

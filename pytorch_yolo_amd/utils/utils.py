@@ -15,8 +15,8 @@ MAX_PER_CLASS = 100        # reference utils.py:247-250
 _ws_cache = {}
 
 
-def _workspace(device, bs, rows, nc):
-    key = (device, bs, rows, nc)
+def _workspace(device, bs, rows, nc, slot=0):
+    key = (device, bs, rows, nc, slot)
     ws = _ws_cache.get(key)
     if ws is None:
         ws = torch.empty(K.nms_workspace_bytes(bs, rows, nc), dtype=torch.uint8, device=device)
@@ -51,6 +51,16 @@ def nms_raw(prediction: torch.Tensor, conf_thres: float, nms_thres: float, inpla
                torch.empty((bs,), dtype=torch.int32, device=dev))
     K.nms_merge(prediction, conf_thres, nms_thres, out[0], out[1], out[2], _workspace(prediction.device, bs, rows, nc),
                 min_wh=MIN_WH, max_per_class=MAX_PER_CLASS, mutate_conf=inplace_conf)
+    return out
+
+
+def nms_launch(prediction, conf_thres, nms_thres, out, slot=0, inplace_conf=False):
+    """Launch the NMS kernels on the current stream into ``out`` = (dets, idx, count); ``slot`` selects a
+    private workspace so that concurrent streams do not share scratch memory."""
+    bs, rows, no = prediction.shape
+    K.nms_merge(prediction, conf_thres, nms_thres, out[0], out[1], out[2],
+                _workspace(prediction.device, bs, rows, no - 5, slot), min_wh=MIN_WH, max_per_class=MAX_PER_CLASS,
+                mutate_conf=inplace_conf)
     return out
 
 
