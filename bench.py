@@ -176,6 +176,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
 
+    traffic = None
+    try:        # HBM bytes of the conv launch list per step, from the committed rocprofv3 --pmc passes (cannot be read live)
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_conv_traffic.json")))
+        if tj["workload"] == args.workload and tj["images_per_gpu"] == bs:
+            traffic = tj["hbm_bytes_per_step"]
+    except (OSError, KeyError, ValueError):
+        pass
+
     if rank == 0:
         total_imgs = bs * world * args.steps
         conv_ms_avg = sum(conv_ms) / len(conv_ms)
@@ -199,7 +207,7 @@ def main():
                        "mean_detections_per_image": round(sum(n_dets) / max(1, len(n_dets)), 1),
                        "streams_per_gpu": n_streams},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "kernel": "conv kernels of one forward (conv_igemm_bf16 / conv3x3_halo / conv1_nchw), union over the streams",
                          "flops_per_step": flops_step, "ms_per_step_conv": round(conv_ms_avg, 4)},
         }

@@ -338,7 +338,7 @@ int yolo_conv::launch_halo3x3(const ConvArgs& a, hipStream_t s) {
   if ((double)d.h * d.w < 0.85 * 256.0 * tiles || (long)d.h * d.w < 80 * 80) return 1;
   if (d.cin % 64 == 0) {
     const bool one = d.cin == 64;
-    if (d.cout % 256 == 0) return one ? launch<16, 16, 256, 4, 2, 64, 1>(a, s) : launch<16, 16, 256, 4, 2, 64, 2>(a, s);
+    if (d.cout % 256 == 0 && !(a.debug & 512)) return one ? launch<16, 16, 256, 4, 2, 64, 1>(a, s) : launch<16, 16, 256, 4, 2, 64, 2>(a, s);
     if (d.cout % 128 == 0) return one ? launch<16, 16, 128, 4, 2, 64, 1>(a, s) : launch<16, 16, 128, 4, 2, 64, 2>(a, s);
     return one ? launch<16, 16, 64, 4, 1, 64, 1>(a, s) : launch<16, 16, 64, 4, 1, 64, 2>(a, s);
   }

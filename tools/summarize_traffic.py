@@ -18,7 +18,8 @@ def load(path, counter):
         if r["Counter_Name"] != counter:
             continue
         k = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
-        k = "conv_igemm_bf16_kernel (all variants)" if "conv_igemm" in k else k.split("(")[0][:60]
+        k = re.sub(r"yolo_conv::", "", k)
+        k = "conv kernels (conv_igemm_bf16 / conv3x3_halo / conv1_nchw)" if re.search(r"conv_igemm|conv3x3_halo|conv1_nchw", k) else k.split("(")[0][:60]
         per[k] = per.get(k, 0.0) + float(r["Counter_Value"])
         n[k] += 1
     return per, n
