@@ -122,3 +122,51 @@ def tiny_mobile_forward(sd, x, anchors=TINY_ANCHORS, n_class=80):
     from .mobilenet import mobilenet_routes
     route1, route2 = mobilenet_routes(sd, x)
     return tiny_mobile_head_forward(sd, route1, route2, max(x.shape[-2:]), anchors, n_class)
+
+
+def yolov3_forward(sd, x, anchors=SPP_ANCHORS, n_class=80):
+    """YOLOv3.forward (eval) — /root/reference/pytorch_yolo/models/yolov3.py:74-116.  Heads 1/2 end in a plain
+    biased 1x1 conv (:38,:55); head 3 ends in a 3x3 ConvBlock (:70)."""
+    img_size = max(x.shape[-2:])
+    x = conv_bn_leaky(sd, "conv1", x)
+    subs = []
+    for i, rep in enumerate(SPP_STAGE_REPEATS, start=1):
+        x, sub = darknet_stage(sd, f"down{i}", x, rep)
+        subs.append(sub)
+    for n in ("conv1", "conv2", "conv3", "conv4", "conv5"):
+        x = conv_bn_leaky(sd, f"seq.{n}", x)
+    b1 = plain_conv1x1(sd, "seq_y1.conv2", conv_bn_leaky(sd, "seq_y1.conv1", x))
+    y = torch.cat([upsample2(conv_bn_leaky(sd, "seqy2_1.conv", x)), subs[3]], 1)          # :87-88
+    for n in ("conv1", "conv2", "conv3", "conv4", "conv5"):
+        y = conv_bn_leaky(sd, f"seqy2_2.{n}", y)
+    b2 = plain_conv1x1(sd, "seqy2_3.conv7", conv_bn_leaky(sd, "seqy2_3.conv6", y))
+    z = torch.cat([upsample2(conv_bn_leaky(sd, "seqy3_1.conv", y)), subs[2]], 1)          # :91-92
+    for n in ("conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7"):
+        z = conv_bn_leaky(sd, f"seqy3_2.{n}", z)
+    outs = [yolo_decode(h, a, n_class, img_size) for h, a in zip((b1, b2, z), anchors)]
+    io, p = zip(*outs)
+    return torch.cat(io, 1), tuple(p)
+
+
+def lite_forward(sd, x, anchors=SPP_ANCHORS, n_class=80):
+    """LiteYOLOv3.forward (eval) — /root/reference/pytorch_yolo/models/lite_yolo.py:79-119."""
+    img_size = max(x.shape[-2:])
+    downs = []
+    for n in ("down1", "down2", "down3"):
+        x = max_pool(conv_bn_leaky(sd, n, x), 2, 2)                                        # ConvPoolBlock
+        downs.append(x)
+    for n in ("down4", "down5"):                                                           # Down, :23-31
+        x = max_pool(conv_bn_leaky(sd, f"{n}.conv_pool", conv_bn_leaky(sd, f"{n}.conv", x)), 2, 2)
+        downs.append(x)
+    x = conv_bn_leaky(sd, "seq.conv1", x)
+    b1 = plain_conv1x1(sd, "seq_y1.conv2", conv_bn_leaky(sd, "seq_y1.conv1", x))
+    y = torch.cat([upsample2(conv_bn_leaky(sd, "seqy2_1.conv", x)), downs[3]], 1)
+    y = conv_bn_leaky(sd, "seqy2_2.conv1.conv2", conv_bn_leaky(sd, "seqy2_2.conv1.conv1", y))   # Conv, :12-20
+    y = conv_bn_leaky(sd, "seqy2_2.conv2", y)
+    b2 = plain_conv1x1(sd, "seqy2_3.conv7", conv_bn_leaky(sd, "seqy2_3.conv6", y))
+    z = torch.cat([upsample2(conv_bn_leaky(sd, "seqy3_1.conv", y)), downs[2]], 1)
+    z = conv_bn_leaky(sd, "seqy3_2.conv1.conv2", conv_bn_leaky(sd, "seqy3_2.conv1.conv1", z))
+    z = conv_bn_leaky(sd, "seqy3_2.conv2", z)                                              # 3x3 ConvBlock head
+    outs = [yolo_decode(h, a, n_class, img_size) for h, a in zip((b1, b2, z), anchors)]
+    io, p = zip(*outs)
+    return torch.cat(io, 1), tuple(p)

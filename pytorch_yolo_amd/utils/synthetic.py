@@ -56,7 +56,8 @@ HEAD_STATS = {
 }
 
 # measured pre-BN variance of the SPP head convs under this generator (1234, 640x640)
-_SPP_HEAD_VAR = {"branch1_2.conv2.": 50.0, "branch2_3.conv7.": 25.0, "branch3_2.conv7.": 6.0}
+_SPP_HEAD_VAR = {"branch1_2.conv2.": 50.0, "branch2_3.conv7.": 25.0, "branch3_2.conv7.": 6.0,
+                 "seqy3_2.conv7.": 6.0, "seqy3_2.conv2.": 6.0}
 
 
 def synth_state_dict(template, seed: int = 1234, n_class: int | None = None):
@@ -76,6 +77,9 @@ def synth_state_dict(template, seed: int = 1234, n_class: int | None = None):
       on the negative side to undo the leaky slope.
     """
     out = OrderedDict()
+    # LiteYOLOv3's third head is seqy3_2.conv2; in YOLOv3 the same name is an ordinary mid layer (its head is conv7)
+    lite_head = not any("seqy3_2.conv7." in k for k in template)
+    _is_head = lambda k: _is_head_key(k) and (lite_head or "seqy3_2.conv2." not in k)   # noqa: E731
     for key, ref in template.items():
         shape = tuple(ref.shape)
         rng = key_rng(seed, key)
@@ -130,10 +134,12 @@ _RESIDUAL_TAIL = re.compile(r"down\d+\.seq\d+\.1\.")
 _HEAD_MARKERS = (
     "branch1_2.conv2.", "branch2_3.conv7.", "branch3_2.conv7.",   # YOLOv3-SPP heads
     "branch1_conv3.", "branch2_conv2.",                            # tiny / MobileNet heads
+    "seq_y1.conv2.", "seqy2_3.conv7.", "seqy3_2.conv7.",           # YOLOv3 heads (plain, plain, ConvBlock)
+    "seqy3_2.conv2.",                                              # LiteYOLOv3 head 3 (ConvBlock); heads 1/2 as YOLOv3
 )
 
 
-def _is_head(key: str) -> bool:
+def _is_head_key(key: str) -> bool:
     return any(m in key for m in _HEAD_MARKERS)
 
 

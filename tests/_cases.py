@@ -21,6 +21,10 @@ MODEL_CASES = {
     "tiny_kd2_nc80":  ("tiny", dict(n_class=80, kernels_divider=2, anchors=TINY_ANCHORS), 1, 96, 128, 13, 23),
     "spp_small":      ("spp", dict(n_class=3, kernels_divider=4, anchors=SPP_ANCHORS), 2, 64, 64, 14, 24),
     "spp_kd2_nc80":   ("spp", dict(n_class=80, kernels_divider=2, anchors=SPP_ANCHORS), 1, 96, 64, 15, 25),
+    # the two model families that reuse the same blocks
+    "yolov3_small":   ("yolov3", dict(n_class=3, kernels_divider=4, anchors=SPP_ANCHORS), 2, 64, 96, 16, 26),
+    "lite_small":     ("lite", dict(n_class=5, kernels_divider=2, anchors=SPP_ANCHORS), 2, 64, 64, 17, 27),
+    "lite_nc80":      ("lite", dict(n_class=80, kernels_divider=1, anchors=SPP_ANCHORS), 1, 128, 96, 18, 28),
 }
 
 # full-size configs of BASELINE.json: only sampled rows + column sums are stored

@@ -5,7 +5,7 @@ Runs only in the build container (needs /root/reference, read-only).  The
 reference package cannot be imported as a whole (its __init__ pulls torchvision
 and a broken openvino converter), so a bare parent package is
 registered and only the hot-path modules are imported:
-    pytorch_yolo.models.{yolov3_tiny,yolov3_spp}   pytorch_yolo.utils.utils
+    pytorch_yolo.models.{yolov3_tiny,yolov3_spp,yolov3,lite_yolo}   pytorch_yolo.utils.utils
 ``pycocotools`` (used by the eval harness only) is stubbed.
 
 Inputs and weights come from seeded generators (tests/_cases.py,
@@ -45,9 +45,11 @@ def import_reference():
     sys.modules["pycocotools.cocoeval"].COCOeval = object
     from pytorch_yolo.models.yolov3_spp import YOLOv3SPP, DownSample
     from pytorch_yolo.models.yolov3_tiny import YOLOv3Tiny
+    from pytorch_yolo.models.yolov3 import YOLOv3
+    from pytorch_yolo.models.lite_yolo import LiteYOLOv3
     from pytorch_yolo.models.yolo_base import MaxPool
     from pytorch_yolo.utils.utils import non_max_suppression
-    return dict(spp=YOLOv3SPP, tiny=YOLOv3Tiny, MaxPool=MaxPool, DownSample=DownSample,
+    return dict(spp=YOLOv3SPP, tiny=YOLOv3Tiny, yolov3=YOLOv3, lite=LiteYOLOv3, MaxPool=MaxPool, DownSample=DownSample,
                 nms=non_max_suppression)
 
 
@@ -109,7 +111,8 @@ def main():
     # ---- state_dict key layout (un-fused and fused) the product must reproduce ------------
     import json
     keys = {}
-    for fam, kw in (("tiny", dict(kernels_divider=2)), ("spp", dict(kernels_divider=4, anchors=C.SPP_ANCHORS))):
+    for fam, kw in (("tiny", dict(kernels_divider=2)), ("spp", dict(kernels_divider=4, anchors=C.SPP_ANCHORS)),
+                    ("yolov3", dict(kernels_divider=4, anchors=C.SPP_ANCHORS)), ("lite", dict(kernels_divider=2, anchors=C.SPP_ANCHORS))):
         m = ref[fam](**kw)
         keys[fam] = {k: list(v.shape) for k, v in m.state_dict().items()}
         m.fuse()

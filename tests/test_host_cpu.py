@@ -69,8 +69,11 @@ def test_c_weight_packer_matches_torch_packer():
 
 def test_state_dict_layout_matches_reference():
     keys = json.load(open(os.path.join(ROOT, "tests", "golden", "state_keys.json")))
+    from pytorch_yolo_amd import LiteYOLOv3, YOLOv3
     for fam, model in (("tiny", YOLOv3Tiny(kernels_divider=2)),
-                       ("spp", YOLOv3SPP(kernels_divider=4, anchors=C.SPP_ANCHORS))):
+                       ("spp", YOLOv3SPP(kernels_divider=4, anchors=C.SPP_ANCHORS)),
+                       ("yolov3", YOLOv3(kernels_divider=4, anchors=C.SPP_ANCHORS)),
+                       ("lite", LiteYOLOv3(kernels_divider=2, anchors=C.SPP_ANCHORS))):
         sd = model.state_dict()
         assert {k: list(v.shape) for k, v in sd.items()} == keys[fam]
         assert list(sd) == list(keys[fam])                       # same order too
