@@ -142,6 +142,15 @@ class YOLOBase(nn.Module):
                 m.fuse()
         self.invalidate()
 
+    # ---- darknet .weights IO (reference yolo_base.py:152-265; see utils/darknet_io.py) -----------------------
+    def load_darknet_weights(self, weights_path, warnings=True):
+        from ..utils.darknet_io import load_darknet_weights
+        return load_darknet_weights(self, weights_path)
+
+    def save_darknet_weights(self, path, warnings=True):
+        from ..utils.darknet_io import save_darknet_weights
+        save_darknet_weights(self, path)
+
     # ---- the path -----------------------------------------------------------------------------------
     def _trace(self, g: engine.Recorder, x):
         raise NotImplementedError

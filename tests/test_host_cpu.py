@@ -168,3 +168,44 @@ def test_synthetic_generator_is_deterministic_and_order_free():
     x = synth_images(2, 32, 48, 21)
     assert x.shape == (2, 3, 32, 48) and 0 <= float(x.min()) and float(x.max()) < 1
     assert torch.equal(x, synth_images(2, 32, 48, 21))
+
+
+def test_darknet_weights_roundtrip_and_layout(tmp_path):
+    """Darknet .weights IO: byte layout and round trip, incl. a backbone-only file."""
+    from pytorch_yolo_amd.utils.darknet_io import darknet_layers
+    from pytorch_yolo_amd.utils.synthetic import synth_state_dict
+    m = YOLOv3Tiny(kernels_divider=8, n_class=3).eval()
+    m.load_state_dict(synth_state_dict(m.state_dict(), 3, n_class=3))
+    m.seen = 12345
+    path = str(tmp_path / "tiny.weights")
+    m.save_darknet_weights(path)
+    raw = np.fromfile(path, dtype=np.int32, count=5)
+    assert raw[3] == 12345
+    data = np.fromfile(path, dtype="<f4")[5:]
+    first = m.sequence_1.conv1.sequence
+    n = first.batch_norm.bias.numel()
+    # per block: bn.bias, bn.weight, running_mean, running_var, conv.weight
+    assert np.array_equal(data[:n], first.batch_norm.bias.detach().numpy())
+    assert np.array_equal(data[n:2 * n], first.batch_norm.weight.detach().numpy())
+    assert np.array_equal(data[2 * n:3 * n], first.batch_norm.running_mean.numpy())
+    assert np.array_equal(data[3 * n:4 * n], first.batch_norm.running_var.numpy())
+    assert np.array_equal(data[4 * n:4 * n + first.conv.weight.numel()], first.conv.weight.detach().numpy().ravel())
+    layers = darknet_layers(m)
+    assert len(layers) == 13 and layers[8] is m.sequence_branch2.branch2_conv1        # /32 branch before /16 branch
+    assert data.size == sum(p.numel() for p in m.parameters()) + sum(b.numel() for k, b in m.named_buffers() if "running" in k)
+    m2 = YOLOv3Tiny(kernels_divider=8, n_class=3).eval()
+    assert m2.load_darknet_weights(path) == 13 and int(m2.seen) == 12345
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        if "num_batches_tracked" not in k:
+            assert torch.equal(a, b), k
+    # backbone-only checkpoint: first 7 blocks
+    upto = sum(sum(t.numel() for t in ([l.sequence.batch_norm.bias] * 4 + [l.sequence.conv.weight])) for l in layers[:7])
+    np.concatenate([raw.view(np.float32), data[:upto]]).astype("<f4").tofile(str(tmp_path / "backbone.weights"))
+    m3 = YOLOv3Tiny(kernels_divider=8, n_class=3).eval()
+    assert m3.load_darknet_weights(str(tmp_path / "backbone.weights")) == 7
+    spp = YOLOv3SPP(kernels_divider=4, n_class=3, anchors=C.SPP_ANCHORS)
+    assert len(darknet_layers(spp)) == 76
+    spp.save_darknet_weights(str(tmp_path / "spp.weights"))
+    spp2 = YOLOv3SPP(kernels_divider=4, n_class=3, anchors=C.SPP_ANCHORS)
+    assert spp2.load_darknet_weights(str(tmp_path / "spp.weights")) == 76
+    assert all(torch.equal(a, b) for (k, a), (_, b) in zip(spp.state_dict().items(), spp2.state_dict().items()) if "tracked" not in k)
