@@ -123,6 +123,12 @@ YOLO_API int yolo_nms_merge(float* pred, int bs, int rows, int nc, float conf_th
                    int max_per_class, int mutate_conf, float* out_dets, int32_t* out_idx,
                    int32_t* out_count, int cap, void* workspace, size_t workspace_bytes, yolo_stream_t s);
 
+/* ---- scale_coords (utils/utils.py:296-303): map kept boxes from the network-input frame back to each original
+ *  image: dets [bs,cap,row_floats] (columns 0..3 = x1,y1,x2,y2) in place; params_dev: device f32 [bs][4] =
+ *  {pad_x, pad_y, gain, n_rows}; do_round = the `.round()` of the caller at utils.py:313. */
+YOLO_API int yolo_scale_coords(float* dets, int bs, int cap, int row_floats, const float* params_dev, int do_round,
+                               yolo_stream_t s);
+
 /* ---- batched launcher: run a recorded list of ops with one FFI crossing (host overhead only). */
 enum { YOLO_OP_CONV = 1, YOLO_OP_MAXPOOL = 2, YOLO_OP_SPP = 3, YOLO_OP_DWCONV = 4, YOLO_OP_CONV1_NCHW = 5 };
 typedef struct YoloOp {

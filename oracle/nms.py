@@ -118,3 +118,14 @@ def non_max_suppression(prediction, conf_thres=0.5, nms_thres=0.5, mutate=True):
         dets.append(d)
         kept.append(k)
     return dets, kept
+
+
+def scale_coords(img1_shape, coords, img0_shape):
+    """scale_coords — utils.py:296-303, fp32 op-for-op (python-float gain / pads cast to fp32 at the tensor op)."""
+    gain = max(img1_shape) / max(img0_shape)
+    out = coords.astype(F32).copy()
+    out[:, [0, 2]] -= F32((img1_shape[1] - img0_shape[1] * gain) / 2)
+    out[:, [1, 3]] -= F32((img1_shape[0] - img0_shape[0] * gain) / 2)
+    out[:, :4] /= F32(gain)
+    out[:, :4] = np.maximum(out[:, :4], F32(0))
+    return out

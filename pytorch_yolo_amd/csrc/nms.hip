@@ -289,6 +289,25 @@ __global__ __launch_bounds__(kMergeThreads) void nms_merge_kernel(const MergeArg
   if (tid == 0) a.out_count[b] = s_nout;
 }
 
+// scale_coords (reference utils/utils.py:296-303), batched: boxes of image b are mapped from the network input
+// frame back to the original image frame: (x - pad_x) / gain, (y - pad_y) / gain, clamped at 0; optional
+// round-half-even like the caller at utils.py:313.  params[b] = {pad_x, pad_y, gain, n_rows}.
+__global__ __launch_bounds__(256) void scale_coords_kernel(float* __restrict__ dets, int row_floats, int cap,
+                                                           const float4* __restrict__ params, int do_round, long total) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int c = (int)(t & 3);
+  const long r = t >> 2;
+  const int b = (int)(r / cap), i = (int)(r - (long)b * cap);
+  const float4 p = params[b];
+  if (i >= (int)p.w) return;
+  float* v = dets + ((long)b * cap + i) * row_floats + c;
+  float x = __fdiv_rn(*v - ((c & 1) ? p.y : p.x), p.z);
+  x = fmaxf(x, 0.f);
+  if (do_round) x = rintf(x);
+  *v = x;
+}
+
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 inline size_t pow2_at_least(size_t v) {
   size_t p = 1;
@@ -362,4 +381,14 @@ extern "C" int yolo_nms_merge(float* pred, int bs, int rows, int nc, float conf_
   a.nms_thres = nms_thres;
   hipLaunchKernelGGL(nms_merge_kernel, dim3((unsigned)bs), dim3(kMergeThreads), 0, st, a);
   return yolo_check_launch("yolo_nms_merge(merge)");
+}
+
+
+extern "C" int yolo_scale_coords(float* dets, int bs, int cap, int row_floats, const float* params_dev, int do_round,
+                                 yolo_stream_t s) {
+  YOLO_REQUIRE(dets && params_dev && bs > 0 && cap > 0 && row_floats >= 4, "scale_coords: bad arguments");
+  const long total = (long)bs * cap * 4;
+  hipLaunchKernelGGL(scale_coords_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, dets,
+                     row_floats, cap, (const float4*)params_dev, do_round, total);
+  return yolo_check_launch("yolo_scale_coords");
 }

@@ -101,3 +101,39 @@ def xywh2xyxy(x):
     y[:, 2] = x[:, 0] + x[:, 2] / 2
     y[:, 3] = x[:, 1] + x[:, 3] / 2
     return y
+
+
+def _scale_params(img1_shape, img0_shape, n_rows):
+    """(pad_x, pad_y, gain, n_rows) exactly as the reference computes them in python floats (utils.py:298-300)."""
+    gain = max(img1_shape) / max(img0_shape)
+    return [(img1_shape[1] - img0_shape[1] * gain) / 2, (img1_shape[0] - img0_shape[0] * gain) / 2, gain, float(n_rows)]
+
+
+def scale_coords(img1_shape, coords, img0_shape, round_result=False):
+    """Drop-in for reference ``scale_coords`` (utils.py:296-303): rescale xyxy boxes (columns 0..3 of ``coords``
+    [n, >=4], modified IN PLACE like the reference) from the network-input frame ``img1_shape`` (h, w) to the
+    original image frame ``img0_shape``.  Runs ``yolo_scale_coords`` on the device."""
+    if not coords.is_cuda:
+        raise RuntimeError("pytorch_yolo_amd.scale_coords runs on a ROCm device only (no CPU fallback)")
+    if coords.dim() != 2 or coords.shape[1] < 4 or coords.dtype != torch.float32 or not coords.is_contiguous():
+        raise RuntimeError("scale_coords: coords must be a contiguous float32 [n, >=4] tensor")
+    n = coords.shape[0]
+    if n == 0:
+        return coords
+    params = torch.tensor([_scale_params(img1_shape, img0_shape, n)], dtype=torch.float32, device=coords.device)
+    from .._lib import check, load
+    check(load().yolo_scale_coords(coords.data_ptr(), 1, n, coords.shape[1], params.data_ptr(), int(round_result),
+                                   K.stream_ptr()), "scale_coords")
+    return coords
+
+
+def scale_detections(dets, count, img1_shape, img0_shapes, round_result=True):
+    """Batched form used after ``nms_raw``: dets [bs,cap,7] in place, one original (h, w) per image; counts are
+    read on the host (they are needed there anyway to split the list)."""
+    counts = count.cpu().tolist()
+    params = torch.tensor([_scale_params(img1_shape, s0, n) for s0, n in zip(img0_shapes, counts)],
+                          dtype=torch.float32, device=dets.device)
+    from .._lib import check, load
+    check(load().yolo_scale_coords(dets.data_ptr(), dets.shape[0], dets.shape[1], dets.shape[2], params.data_ptr(),
+                                   int(round_result), K.stream_ptr()), "scale_coords")
+    return dets

@@ -104,3 +104,14 @@ def nms_case_inputs(name: str):
     if name == "nms_none_pass":
         pred[1, :, 4] *= np.float32(1e-3)
     return pred, conf, iou
+
+
+# scale_coords (utils.py:296-303): (network input (h, w), original image (h, w))
+SCALE_CASES = [((416, 416), (480, 640)), ((640, 640), (1080, 1920)), ((320, 416), (375, 500)), ((640, 640), (333, 500))]
+
+
+def scale_coords_boxes(n: int = 200, seed: int = 41) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    b = rng.uniform(-20, 660, (n, 4)).astype(np.float32)
+    b[:, 2:] = b[:, :2] + rng.uniform(1, 300, (n, 2)).astype(np.float32)
+    return b

@@ -48,8 +48,8 @@ def import_reference():
     from pytorch_yolo.models.yolov3 import YOLOv3
     from pytorch_yolo.models.lite_yolo import LiteYOLOv3
     from pytorch_yolo.models.yolo_base import MaxPool
-    from pytorch_yolo.utils.utils import non_max_suppression
-    return dict(spp=YOLOv3SPP, tiny=YOLOv3Tiny, yolov3=YOLOv3, lite=LiteYOLOv3, MaxPool=MaxPool, DownSample=DownSample,
+    from pytorch_yolo.utils.utils import non_max_suppression, scale_coords
+    return dict(scale_coords=scale_coords, spp=YOLOv3SPP, tiny=YOLOv3Tiny, yolov3=YOLOv3, lite=LiteYOLOv3, MaxPool=MaxPool, DownSample=DownSample,
                 nms=non_max_suppression)
 
 
@@ -105,7 +105,10 @@ def main():
     xin = synth_images(1, 16, 16, 6, channels=4)
     with torch.no_grad():
         ds_x, ds_sub = ds(xin)
-    save("kat", maxpool21=mp, nms_kat=kat, nms_kat_col4=pred[0, :, 4].numpy(),
+    sc_in = C.scale_coords_boxes()
+    sc = {f"scale_{i}": ref["scale_coords"](s1, torch.from_numpy(sc_in.copy()), s0).numpy()
+          for i, (s1, s0) in enumerate(C.SCALE_CASES)}
+    save("kat", **sc, maxpool21=mp, nms_kat=kat, nms_kat_col4=pred[0, :, 4].numpy(),
          downsample_x=ds_x.numpy(), downsample_sub=ds_sub.numpy())
 
     # ---- state_dict key layout (un-fused and fused) the product must reproduce ------------

@@ -238,6 +238,25 @@ def test_nms_kat_and_non_mutating_default():
     assert np.allclose(after[0, :, 4], C.NMS_KAT_COL4, atol=1e-6)
 
 
+def test_scale_coords_bit_exact():
+    """yolo_scale_coords vs the reference golden (utils.py:296-303) and the batched form with rounding."""
+    from oracle import nms as onms
+    from pytorch_yolo_amd.utils.utils import scale_coords, scale_detections
+    g = load_golden("kat")
+    boxes = C.scale_coords_boxes()
+    for i, (s1, s0) in enumerate(C.SCALE_CASES):
+        t = torch.from_numpy(np.concatenate([boxes, np.ones((len(boxes), 3), np.float32)], 1)).to(DEV)
+        out = scale_coords(s1, t, s0).cpu().numpy()
+        assert np.array_equal(out[:, :4], g[f"scale_{i}"]) and np.all(out[:, 4:] == 1)
+    dets = torch.from_numpy(np.stack([np.concatenate([boxes, np.zeros((len(boxes), 3), np.float32)], 1)] * 2)).to(DEV)
+    cnt = torch.tensor([50, 200], dtype=torch.int32, device=DEV)
+    scale_detections(dets, cnt, (640, 640), [(1080, 1920), (333, 500)], round_result=True)
+    d = dets.cpu().numpy()
+    assert np.array_equal(d[0, :50, :4], np.round(onms.scale_coords((640, 640), boxes[:50], (1080, 1920))))
+    assert np.array_equal(d[0, 50:, :4], boxes[50:])                               # rows beyond the count untouched
+    assert np.array_equal(d[1, :, :4], np.round(onms.scale_coords((640, 640), boxes, (333, 500))))
+
+
 def test_nms_many_survivors_global_sort_path():
     """> 8192 survivors in one image: the keys are sorted in the global workspace instead of LDS."""
     from oracle import nms as onms

@@ -106,3 +106,10 @@ def test_nms_cases(name):
         assert dets[1] is None and dets[0] is not None
     if name == "nms_dense_nc3":
         assert max(len(d) for d in dets) <= 3 * 100
+
+
+def test_scale_coords_kat():
+    g = load_golden("kat")
+    boxes = C.scale_coords_boxes()
+    for i, (s1, s0) in enumerate(C.SCALE_CASES):
+        assert np.array_equal(onms.scale_coords(s1, boxes, s0), g[f"scale_{i}"]), (s1, s0)
