@@ -166,29 +166,44 @@ struct DecodeArgs {
   long total;
 };
 
+// Thread = one head channel c = anchor*(5+nc) + k (constant over the block's pixels, so the anchor / role
+// split costs nothing per element); a block walks kDecodePix consecutive pixels.  Reads are 1 KiB runs per
+// pixel, the p and io stores 340-byte runs per (pixel, anchor) that continue with the next pixel.
+constexpr int kDecodePix = 16;
+
 __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
-  // grid.y = image*na + anchor; grid.x covers the ny*nx*(5+nc) elements of that plane (32-bit index math)
-  const uint32_t no = (uint32_t)a.nc + 5u;
-  const uint32_t plane = (uint32_t)a.ny * (uint32_t)a.nx * no;
-  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-  if (t >= plane) return;
-  const uint32_t b = blockIdx.y / (uint32_t)a.na, an = blockIdx.y - b * (uint32_t)a.na;
-  const uint32_t cell = t / no, k = t - cell * no;
-  const uint32_t gy = cell / (uint32_t)a.nx, gx = cell - gy * (uint32_t)a.nx;
-  const float raw = a.head[((size_t)b * a.ny * a.nx + cell) * a.head_ct + an * no + k];
-  const size_t pidx = ((size_t)b * a.na + an) * plane + t;
-  if (a.p) a.p[pidx] = raw;
-  float v;
-  if (k < 2) {
-    v = (1.f / (1.f + expf(-raw)) + (float)(k == 0 ? gx : gy)) * a.stride;   // :91,:94
-  } else if (k < 4) {
-    v = (expf(raw) * (k == 2 ? a.anchor_w[an] : a.anchor_h[an])) * a.stride;  // :92,:94
-  } else {
-    v = 1.f / (1.f + expf(-raw));                                             // :93
-    if (a.nc == 1 && k == 5) v = 1.f;                                         // :95-96
+  const int no = a.nc + 5;
+  for (int c = threadIdx.x; c < a.na * no; c += 256) {   // one pass for na*(5+nc) <= 256 (nc <= 80)
+  const int an = c / no, k = c - an * no;
+  const float anchor = k == 2 ? a.anchor_w[an] : a.anchor_h[an];
+  const int cells = a.ny * a.nx;
+  const long total_pix = (long)a.total;                 // bs * ny * nx
+  const long pix0 = (long)blockIdx.x * kDecodePix;
+  float raw[kDecodePix];
+#pragma unroll
+  for (int i = 0; i < kDecodePix; ++i)
+    raw[i] = pix0 + i < total_pix ? a.head[(pix0 + i) * a.head_ct + c] : 0.f;
+#pragma unroll
+  for (int i = 0; i < kDecodePix; ++i) {
+    const long pix = pix0 + i;
+    if (pix >= total_pix) break;
+    const int b = (int)(pix / cells), cell = (int)(pix - (long)b * cells);
+    const int gy = cell / a.nx, gx = cell - gy * a.nx;
+    const float r = raw[i];
+    float v;
+    if (k < 2) {
+      v = (1.f / (1.f + expf(-r)) + (float)(k == 0 ? gx : gy)) * a.stride;   // :91,:94
+    } else if (k < 4) {
+      v = (expf(r) * anchor) * a.stride;                                      // :92,:94
+    } else {
+      v = 1.f / (1.f + expf(-r));                                             // :93
+      if (a.nc == 1 && k == 5) v = 1.f;                                       // :95-96
+    }
+    const long plane_elem = (long)cell * no + k;
+    if (a.p) a.p[((long)b * a.na + an) * cells * no + plane_elem] = r;
+    a.io[((long)b * a.io_rows_total + a.io_row_offset + (long)an * cells) * no + plane_elem] = v;
   }
-  const size_t row = (size_t)a.io_row_offset + (size_t)an * a.ny * a.nx + cell;
-  a.io[((size_t)b * a.io_rows_total + row) * no + k] = v;
+  }
 }
 
 inline unsigned blocks_for(long total) { return (unsigned)((total + 255) / 256); }
@@ -273,9 +288,9 @@ extern "C" int yolo_decode_fwd(const float* head, int head_c_total, const float*
     a.anchor_w[i] = anchors_px[2 * i] / stride_px;
     a.anchor_h[i] = anchors_px[2 * i + 1] / stride_px;
   }
-  a.total = (long)bs * na * ny * nx * (5 + nc);
-  const long plane = (long)ny * nx * (5 + nc);
-  YOLO_REQUIRE(plane < 0x7fffffffL && (long)bs * na <= 65535, "decode: head too large");
-  hipLaunchKernelGGL(decode_kernel, dim3(blocks_for(plane), (unsigned)(bs * na)), dim3(256), 0, (hipStream_t)s, a);
+  a.total = (long)bs * ny * nx;                          // pixels
+  const long blocks = (a.total + kDecodePix - 1) / kDecodePix;
+  YOLO_REQUIRE(blocks < 0x7fffffffL, "decode: head too large");
+  hipLaunchKernelGGL(decode_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, a);
   return yolo_check_launch("yolo_decode_fwd");
 }
