@@ -78,29 +78,19 @@ __device__ __forceinline__ void prefetch_residual(const ConvArgs& a, ResPrefetch
   }
 }
 
-template <int MI, int NI, int TM, typename PixOf>
-__device__ __forceinline__ void epilogue_lds(const ConvArgs& a, const f32x16 (&acc)[MI][NI], char* stg, int lane,
-                                             int cout0, PixOf pix_of, const ResPrefetch<MI, TM>* rpre = nullptr) {
+// Core of the LDS-staged epilogue: write_slab(i) puts act(acc + bias) of 32-cout slab i as fp32 into the wave's
+// private slab [TM pixel rows][32 couts] (row pitch kEpiPitch); the coalesced phase below is layout-agnostic.
+template <int MI, int TM, typename WriteSlab, typename PixOf>
+__device__ __forceinline__ void epilogue_lds_core(const ConvArgs& a, char* stg, int lane, int cout0, WriteSlab write_slab,
+                                                  PixOf pix_of, const ResPrefetch<MI, TM>* rpre) {
   const YoloConvDesc& d = a.d;
-  const int r32 = lane & 31, khalf = lane >> 5;
   const int crow = lane >> 2, cchunk = lane & 3;   // coalesced phase: 16 pixel rows x 4 chunks of 8 couts
   const int hw_out = d.ho * d.wo;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int cbase = cout0 + i * 32;              // first cout of this slab
     if (cbase >= d.cout) continue;                 // cout % 32 == 0: a slab is all-or-nothing
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int cl = g4 * 8 + khalf * 4;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + cbase + cl);
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[i][j][g4 * 4 + e] + bv[e], d.act);
-        *reinterpret_cast<f32x4*>(stg + (j * 32 + r32) * kEpiPitch + cl * 4) = v;
-      }
-    }
+    write_slab(i, cbase);
     __builtin_amdgcn_wave_barrier();               // LDS ops of one wave execute in order
     const long cofs = cbase + cchunk * 8;
 #pragma unroll
@@ -141,6 +131,50 @@ __device__ __forceinline__ void epilogue_lds(const ConvArgs& a, const f32x16 (&a
     }
     __builtin_amdgcn_wave_barrier();
   }
+}
+
+// 32x32x16 accumulators: acc[i][j] = couts [32i, 32i+32) x pixels [32j, 32j+32); lane = pixel column r32,
+// register e -> cout (e&3) + 8*(e>>2) + 4*(lane>>5).
+template <int MI, int NI, int TM, typename PixOf>
+__device__ __forceinline__ void epilogue_lds(const ConvArgs& a, const f32x16 (&acc)[MI][NI], char* stg, int lane,
+                                             int cout0, PixOf pix_of, const ResPrefetch<MI, TM>* rpre = nullptr) {
+  const int r32 = lane & 31, khalf = lane >> 5;
+  epilogue_lds_core<MI, TM>(a, stg, lane, cout0, [&](int i, int cbase) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int cl = g4 * 8 + khalf * 4;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + cbase + cl);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[i][j][g4 * 4 + e] + bv[e], a.d.act);
+        *reinterpret_cast<f32x4*>(stg + (j * 32 + r32) * kEpiPitch + cl * 4) = v;
+      }
+    }
+  }, pix_of, rpre);
+}
+
+// 16x16x32 accumulators: acc[i][j] = couts [16i, 16i+16) x pixels [16j, 16j+16); lane = pixel column lane&15,
+// register e -> cout 4*(lane>>4) + e.  MI16 = 2*MI cout tiles, NI16 pixel tiles.
+template <int MI, int NI16, int TM, typename PixOf>
+__device__ __forceinline__ void epilogue_lds16(const ConvArgs& a, const f32x4 (&acc)[2 * MI][NI16], char* stg, int lane,
+                                               int cout0, PixOf pix_of) {
+  const int c16 = lane & 15, q = lane >> 4;
+  epilogue_lds_core<MI, TM>(a, stg, lane, cout0, [&](int i, int cbase) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int cl = t * 16 + q * 4;
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + cbase + cl);
+#pragma unroll
+      for (int j = 0; j < NI16; ++j) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[2 * i + t][j][e] + bv[e], a.d.act);
+        *reinterpret_cast<f32x4*>(stg + (j * 16 + c16) * kEpiPitch + cl * 4) = v;
+      }
+    }
+  }, pix_of, (const ResPrefetch<MI, TM>*)nullptr);
 }
 
 // XCD-aware block order (bijective for any grid): blocks with equal blockIdx%8 share an XCD / L2 and get a

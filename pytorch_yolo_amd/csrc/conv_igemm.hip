@@ -32,7 +32,7 @@ namespace {
 // the instruction's scalar offset: ~3 VALU per LDS-DMA instead of ~15.
 // LDS_EPI (bf16 output, cout % 32 == 0): the finished tile goes registers -> LDS (fp32) -> global so that
 // residual read, pre-add copy and store are 16-byte-per-lane accesses over whole channel runs.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int NS, bool FAST, bool LDS_EPI>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int NS, bool FAST, bool LDS_EPI, bool MFMA16 = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel(const ConvArgs a) {
   constexpr int NW = WAVES_M * WAVES_N;
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
@@ -181,13 +181,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel
     }
   };
 
-  f32x16 acc[MI][NI];
+  static_assert(!MFMA16 || LDS_EPI, "the 16x16x32 path only has the LDS epilogue");
+  constexpr int MI16 = MFMA16 ? TN / 16 : 1, NI16 = MFMA16 ? TM / 16 : 1;
+  f32x16 acc[MFMA16 ? 1 : MI][MFMA16 ? 1 : NI];
+  f32x4 acc16[MI16][NI16];
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+  for (int i = 0; i < (MFMA16 ? 1 : MI); ++i)
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
+    for (int j = 0; j < (MFMA16 ? 1 : NI); ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < MI16; ++i)
+#pragma unroll
+    for (int j = 0; j < NI16; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc16[i][j][e] = 0.f;
 
   const int r32 = lane & 31, khalf = lane >> 5;
   const int steps = a.steps;
@@ -221,6 +230,36 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel
     if (more) stage_begin();
     const char* wbuf = smem + buf * STAGE_B;
     const char* xbuf = wbuf + BNL * ROWB;
+    if constexpr (MFMA16) {
+      // v_mfma_f32_16x16x32_bf16: lane = (row l&15, k-chunk l>>4); one instruction eats 32 k of a 16x16 tile
+      const int c16 = lane & 15, q = lane >> 4;
+#pragma unroll
+      for (int kk = 0; kk < BK / 32; ++kk) {
+        if (more) issue(nb, s + NS - 1, kk * LPS / (BK / 32), (kk + 1) * LPS / (BK / 32));
+        if (!(a.debug & 4)) {
+          const int g = kk * 4 + q;
+          bf16x8 wf[MI16], xf[NI16];
+#pragma unroll
+          for (int i = 0; i < MI16; ++i) {
+            const int R = wn * TN + i * 16 + c16;
+            const int sw = (BK == 32) ? ((R >> 2) & 3) : ((R >> 1) & 7);
+            wf[i] = *reinterpret_cast<const bf16x8*>(wbuf + R * ROWB + ((g ^ sw) << 4));
+          }
+#pragma unroll
+          for (int j = 0; j < NI16; ++j) {
+            const int R = wm * TM + j * 16 + c16;
+            const int sw = (BK == 32) ? ((R >> 2) & 3) : ((R >> 1) & 7);
+            xf[j] = *reinterpret_cast<const bf16x8*>(xbuf + R * ROWB + ((g ^ sw) << 4));
+          }
+#pragma unroll
+          for (int i = 0; i < MI16; ++i)
+#pragma unroll
+            for (int j = 0; j < NI16; ++j)
+              acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc16[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       if (more) issue(nb, s + NS - 1, ks * LPS / KS, (ks + 1) * LPS / KS);
@@ -257,14 +296,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("" ::"v"(acc[i][j]));   // keep the accumulators live in the timing-only build path
+        if (!MFMA16) asm volatile("" ::"v"(acc[i][j]));   // keep the accumulators live in the timing-only build path
+#endif
+      }
+#pragma unroll
+    for (int i = 0; i < MI16; ++i)
+#pragma unroll
+      for (int j = 0; j < NI16; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (MFMA16) asm volatile("" ::"v"(acc16[i][j]));
 #endif
       }
     return;
   }
   // ---- epilogue: lane = pixel (col), registers = couts (row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) ----
   const bool f32_out = d.out_dtype == YOLO_DT_F32;
-  if constexpr (LDS_EPI) {
+  if constexpr (LDS_EPI && MFMA16) {
+    __syncthreads();
+    epilogue_lds16<MI, NI16, TM>(a, acc16, smem + wave * (TM * kEpiPitch), lane, n0 + wn * TN, pix_of);
+  } else if constexpr (LDS_EPI) {
     __syncthreads();                                 // every wave is done with the last stage: LDS is free
     epilogue_lds<MI, NI, TM>(a, acc, smem + wave * (TM * kEpiPitch), lane, n0 + wn * TN, pix_of);
   } else {
@@ -338,7 +388,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int NS, bool FAST, bool LDS_EPI>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int NS, bool FAST, bool LDS_EPI, bool MFMA16 = false>
 int launch_cfg(const ConvArgs& a, hipStream_t s) {
   const int m_tiles = (a.M + BM - 1) / BM;
   ConvArgs b = a;
@@ -346,7 +396,7 @@ int launch_cfg(const ConvArgs& a, hipStream_t s) {
   b.steps = (a.d.ksize * a.d.ksize * a.d.cin + BK - 1) / BK;   // kpad >= steps*BK: the K tail is zero-padded
   const long grid = (long)m_tiles * b.n_tiles;
   if (grid > 0x7fffffffL) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv grid too large");
-  hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, BK, NS, FAST, LDS_EPI>), dim3((unsigned)grid),
+  hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, BK, NS, FAST, LDS_EPI, MFMA16>), dim3((unsigned)grid),
                      dim3(64 * WAVES_M * WAVES_N), 0, s, b);
   return yolo_check_launch("yolo_conv2d_fwd");
 }
@@ -424,6 +474,15 @@ int yolo_conv2d_launch(const void* x, const void* w, const float* bias, const vo
     // short-K 1x1 layers on big maps are latency/HBM-bound: 256x128 tiles with 32-deep stages keep
     // 16 waves per CU resident (two 8-wave blocks), which hides the per-tile prologue/epilogue
     if (d.ksize == 1 && d.cin <= 512 && M >= 40000) pick = 9;
+  }
+  // 16x16x32 MFMA mainloop (same LDS traffic and cycles per FLOP as 32x32x16; the chip holds a higher clock on
+  // it: +2..3 % measured on every shape).  YOLO_CONV_DEBUG bit 2048 falls back to 32x32x16.
+  if (epi && !(conv_debug_flags & 2048)) {
+    switch (pick) {
+      case 5: return launch_cfg<256, 256, 4, 2, 64, 2, true, true, true>(a, s);
+      case 9: return launch_cfg<256, 128, 4, 2, 32, 2, true, true, true>(a, s);
+      default: return launch_cfg<128, 128, 2, 2, 64, 2, true, true, true>(a, s);
+    }
   }
   switch (pick) {
     case 3: return YOLO_CFG(256, 128, 4, 2, 64, 2, true);
