@@ -122,8 +122,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv3x3_halo_kernel(co
     const int yy = y0 + q / TW, xx = x0 + q % TW;
     return (yy < d.h && xx < d.w) ? ((long)(b * d.h + yy) * d.w + xx) : -1L;
   };
-  ResPrefetch<MI, TM> rpre;
-  const bool pre_res = a.res != nullptr && !(a.debug & 128);
 
   int wb = 0;
   for (int c = 0; c < n_chunks; ++c) {
@@ -133,8 +131,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv3x3_halo_kernel(co
     for (int tap = 0; tap < 9; ++tap) {
       wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();       // stage (c,tap) is in LDS; every wave finished reading stage (c,tap)-1
-      // residual tile -> registers two taps before the end: it lands under the MFMAs of taps 6..7
-      if (pre_res && c == n_chunks - 1 && tap == 6) prefetch_residual<MI, TM>(a, rpre, lane, n0 + wn * TN, pix_of);
       // prefetch: weights of the next step, and 1/9 of the next chunk's halo (HB == 2)
       if (tap < 8) {
         issue_w(wb ^ 1, c, tap + 1);
@@ -189,11 +185,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv3x3_halo_kernel(co
     return;
   }
   __syncthreads();
-  epilogue_lds<MI, NI, TM>(a, acc, smem + wave * (TM * kEpiPitch), lane, n0 + wn * TN, [&](int row) -> long {
-    const int q = wm * TM + row;
-    const int yy = y0 + q / TW, xx = x0 + q % TW;
-    return (yy < d.h && xx < d.w) ? ((long)(b * d.h + yy) * d.w + xx) : -1L;
-  });
+  epilogue_lds<MI, NI, TM>(a, acc, smem + wave * (TM * kEpiPitch), lane, n0 + wn * TN, pix_of);
 }
 
 // ---------------------------------------------------------------------------------------------------
