@@ -474,6 +474,8 @@ int yolo_conv2d_launch(const void* x, const void* w, const float* bias, const vo
     // short-K 1x1 layers on big maps are latency/HBM-bound: 256x128 tiles with 32-deep stages keep
     // 16 waves per CU resident (two 8-wave blocks), which hides the per-tile prologue/epilogue
     if (d.ksize == 1 && d.cin <= 512 && M >= 40000) pick = 9;
+    // tiny grids (1x1 layers on the 20x20 maps): 64x64 tiles quadruple the block count so the chip fills
+    if (d.ksize == 1 && ((M + 127) / 128) * ((d.cout + 127) / 128) < 256) pick = 11;
   }
   // 16x16x32 MFMA mainloop (same LDS traffic and cycles per FLOP as 32x32x16; the chip holds a higher clock on
   // it: +2..3 % measured on every shape).  YOLO_CONV_DEBUG bit 2048 falls back to 32x32x16.
@@ -481,6 +483,7 @@ int yolo_conv2d_launch(const void* x, const void* w, const float* bias, const vo
     switch (pick) {
       case 5: return launch_cfg<256, 256, 4, 2, 64, 2, true, true, true>(a, s);
       case 9: return launch_cfg<256, 128, 4, 2, 32, 2, true, true, true>(a, s);
+      case 11: return launch_cfg<64, 64, 2, 2, 64, 2, true, true, true>(a, s);
       default: return launch_cfg<128, 128, 2, 2, 64, 2, true, true, true>(a, s);
     }
   }
@@ -488,6 +491,8 @@ int yolo_conv2d_launch(const void* x, const void* w, const float* bias, const vo
     case 3: return YOLO_CFG(256, 128, 4, 2, 64, 2, true);
     case 7: return YOLO_CFG(128, 128, 2, 2, 32, 2, true);
     case 8: return YOLO_CFG(128, 64, 2, 2, 64, 2, true);
+    case 10: return YOLO_CFG(64, 128, 2, 2, 64, 2, true);
+    case 11: return YOLO_CFG(64, 64, 2, 2, 64, 2, true);
     case 9: return YOLO_CFG(256, 128, 4, 2, 32, 2, true);
     case 5: return YOLO_CFG(256, 256, 4, 2, 64, 2, true);
     default: return YOLO_CFG(128, 128, 2, 2, 64, 2, true);
