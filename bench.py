@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from pytorch_yolo_amd import YOLOv3SPP, YOLOv3Tiny, YOLOv3TinyMobile          # noqa: E402
-from pytorch_yolo_amd.distributed import gather_detections                  # noqa: E402
+from pytorch_yolo_amd.distributed import PipelinedGather                    # noqa: E402
 from pytorch_yolo_amd.utils.synthetic import synth_images, synth_state_dict  # noqa: E402
 from pytorch_yolo_amd.utils.utils import nms_capacity, nms_raw               # noqa: E402
 from pytorch_yolo_amd import kernels as K                                    # noqa: E402
@@ -110,7 +110,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # under torch.distributed.run (RANK set) the sharded path runs even with one rank, so that it can be rehearsed
+    # on a single GPU; the plain `python bench.py` of the N=1 contract stays collective-free
+    sharded = world > 1 or ("RANK" in os.environ and os.environ.get("YOLO_BENCH_SHARDED_AT_1") == "1")
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -136,20 +139,25 @@ def main():
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_streams)]
           for _ in range(total_steps)]
     ref = torch.cuda.Event(enable_timing=True)
-    free_run = world == 1          # no per-step join: the S sub-batch pipelines run freely until the final sync
+    # no per-step join: the S sub-batch pipelines run freely until the final sync; when sharded, the detections
+    # all-gather of every step rides a side stream (distributed.PipelinedGather) instead of joining them
+    gatherer = PipelinedGather(bs, cap, n_streams, dev) if sharded else None
 
     def step(i):
         """Per stream: conv1 (reads the NCHW batch) -> 75 conv launches + SPP -> 3 decodes -> NMS on its sub-batch
         (-> join + all-gather when sharded over ranks).  HIP events bracket every stream's conv launch list on
         the stream it is launched on."""
-        plan.launch_detect(x, io, ps, nms_out, CONF_THRES, NMS_THRES, timing=ev[i], join=not free_run)
-        if world > 1:
-            return gather_detections(nms_out[0], nms_out[2])
-        return nms_out[0], nms_out[2]
+        if gatherer is None:
+            plan.launch_detect(x, io, ps, nms_out, CONF_THRES, NMS_THRES, timing=ev[i], join=False)
+            return nms_out[0], nms_out[2]
+        plan.launch_detect(x, io, ps, nms_out, CONF_THRES, NMS_THRES, timing=ev[i], join=False,
+                           after_nms=gatherer.begin(nms_out))
+        all_dets, all_count, _ = gatherer.exchange()
+        return all_dets, all_count
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -172,7 +180,7 @@ def main():
     n_dets = counts.cpu().tolist()
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if sharded:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
 
@@ -203,7 +211,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl["name"], "images_per_gpu": bs, "global_batch": bs * world,
                        "n_class": nc, "conf_thres": CONF_THRES, "nms_thres": NMS_THRES,
-                       "sharding": f"batch x{world}" + (" + RCCL all-gather of detections" if world > 1 else ""),
+                       "sharding": f"batch x{world}" + (" + RCCL all-gather of detections (side stream)" if sharded else ""),
                        "mean_detections_per_image": round(sum(n_dets) / max(1, len(n_dets)), 1),
                        "streams_per_gpu": n_streams},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -214,7 +222,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 

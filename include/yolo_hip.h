@@ -102,6 +102,18 @@ YOLO_API int yolo_maxpool_fwd(const void* x, void* y, int n, int h, int w, int c
  *      slice [3c,4c) already holds x; writes pool5 -> [0,c), pool9 -> [c,2c), pool13 -> [2c,3c). */
 YOLO_API int yolo_spp_fwd(void* buf, int n, int h, int w, int c, yolo_stream_t s);
 
+/* ---- one Darknet residual unit in one launch (models/yolov3_spp.py:17-32: ConvBlock 1x1 C->C/2, ConvBlock 3x3
+ *  C/2->C, Add):  y = x + act(conv3x3(act(conv1x1(x,W1)+b1), W2) + b2);  y_preadd (optional) = the 3x3 output
+ *  before the add (the reference returns it from the last unit of a DownSample stage).
+ *  d describes the 3x3/s1/p1 conv: cin = C/2, cout = C, kpad/cout_pad = packing of W2; its INPUT view fields
+ *  (in_c_total/in_c_offset) describe x (C channels); res_* fields are ignored.  W1 is packed like any 1x1
+ *  ([cout_pad1][kpad1]).  y must not alias x.  yolo_resunit_supported(): C in {64,128,256} on maps >= 80x80 that
+ *  tile well by 16x16; other shapes use two yolo_conv2d_fwd calls. */
+YOLO_API int yolo_resunit_supported(int c, int h, int w);
+YOLO_API int yolo_resunit_fwd(const void* x, const void* w1_packed, const float* b1, const void* w2_packed,
+                              const float* b2, void* y, void* y_preadd, const YoloConvDesc* d, int kpad1,
+                              int cout_pad1, yolo_stream_t s);
+
 /* ---- YOLOLayer.forward eval branch (models/yolo_layer.py:57-69,90-111).
  *  head: f32 NHWC [bs,ny,nx,head_c_total], channel a*(5+nc)+k.
  *  io:   f32 [bs, io_rows_total, 5+nc]; this head fills rows [io_row_offset, +na*ny*nx).
@@ -130,13 +142,17 @@ YOLO_API int yolo_scale_coords(float* dets, int bs, int cap, int row_floats, con
                                yolo_stream_t s);
 
 /* ---- batched launcher: run a recorded list of ops with one FFI crossing (host overhead only). */
-enum { YOLO_OP_CONV = 1, YOLO_OP_MAXPOOL = 2, YOLO_OP_SPP = 3, YOLO_OP_DWCONV = 4, YOLO_OP_CONV1_NCHW = 5 };
+enum { YOLO_OP_CONV = 1, YOLO_OP_MAXPOOL = 2, YOLO_OP_SPP = 3, YOLO_OP_DWCONV = 4, YOLO_OP_CONV1_NCHW = 5,
+       YOLO_OP_RESUNIT = 6 };
 typedef struct YoloOp {
   int32_t kind, _pad;
   const void* x; const void* w; const float* bias; const void* residual; void* y; void* y_aux;
   YoloConvDesc conv;             /* kind CONV; DWCONV/MAXPOOL/SPP reuse the geometry fields
                                     (ksize/stride/pad, act, views); MAXPOOL dilation = upsample2x field;
-                                    CONV1_NCHW: x = f32 NCHW input, res_c_total = real input channels */
+                                    CONV1_NCHW: x = f32 NCHW input, res_c_total = real input channels;
+                                    RESUNIT: the unit's 3x3 (w/bias = W2/b2), see yolo_resunit_fwd */
+  const void* w_pre; const float* bias_pre;   /* RESUNIT: packed W1 / b1 of the leading 1x1 */
+  int32_t kpad_pre, cout_pad_pre;
 } YoloOp;
 YOLO_API int yolo_run_ops(const YoloOp* ops, int n_ops, yolo_stream_t s);
 

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libyolo_hip.so")
 
 ACT_NONE, ACT_LEAKY01, ACT_RELU6 = 0, 1, 2
 DT_BF16, DT_F32 = 0, 1
-OP_CONV, OP_MAXPOOL, OP_SPP, OP_DWCONV, OP_CONV1_NCHW = 1, 2, 3, 4, 5
+OP_CONV, OP_MAXPOOL, OP_SPP, OP_DWCONV, OP_CONV1_NCHW, OP_RESUNIT = 1, 2, 3, 4, 5, 6
 
 
 class YoloConvDesc(C.Structure):
@@ -28,7 +28,8 @@ class YoloOp(C.Structure):
     _fields_ = [("kind", C.c_int32), ("_pad", C.c_int32),
                 ("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p),
                 ("residual", C.c_void_p), ("y", C.c_void_p), ("y_aux", C.c_void_p),
-                ("conv", YoloConvDesc)]
+                ("conv", YoloConvDesc),
+                ("w_pre", C.c_void_p), ("bias_pre", C.c_void_p), ("kpad_pre", C.c_int32), ("cout_pad_pre", C.c_int32)]
 
 
 # symbol -> (restype, argtypes); kept in one table so tests can check it against the header
@@ -40,6 +41,8 @@ SIGNATURES = {
     "yolo_conv1_nchw_f32_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.POINTER(YoloConvDesc), C.c_void_p]),
     "yolo_pack_conv_weight_f32": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
+    "yolo_resunit_supported": (C.c_int, [C.c_int] * 3),
+    "yolo_resunit_fwd": (C.c_int, [C.c_void_p] * 7 + [C.POINTER(YoloConvDesc), C.c_int, C.c_int, C.c_void_p]),
     "yolo_dwconv3x3_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 12 + [C.c_void_p]),
     "yolo_maxpool_fwd": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 14 + [C.c_void_p]),
     "yolo_spp_fwd": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),

@@ -19,6 +19,7 @@ SOURCES = {
     "runtime.hip": [],
     "conv_igemm.hip": [],
     "conv3x3_halo.hip": [],
+    "conv_resunit.hip": [],
     "pointwise.hip": [],
     "nms.hip": ["-ffp-contract=off"],
 }

@@ -40,6 +40,9 @@ extern "C" int yolo_run_ops(const YoloOp* ops, int n_ops, yolo_stream_t s) {
         rc = yolo_dwconv3x3_fwd(o.x, (const float*)o.w, o.bias, o.y, d.n, d.h, d.w, d.cin, d.in_c_total, d.in_c_offset, d.ho,
                                 d.wo, d.out_c_total, d.out_c_offset, d.stride, d.act, s);
         break;
+      case YOLO_OP_RESUNIT:
+        rc = yolo_resunit_fwd(o.x, o.w_pre, o.bias_pre, o.w, o.bias, o.y, o.y_aux, &d, o.kpad_pre, o.cout_pad_pre, s);
+        break;
       default:
         return yolo_set_error(YOLO_E_ARG, "run_ops: op %d has unknown kind %d", i, o.kind);
     }

@@ -39,6 +39,64 @@ def gather_detections(dets: torch.Tensor, count: torch.Tensor, group=None, gathe
     return all_dets, all_count
 
 
+class PipelinedGather:
+    """The same all-gather, taken off the critical path of a stream of batches (bench.py, serving loops).
+
+    ``detect`` runs S free-running sub-batch pipelines per GPU (engine.StreamedPlan); joining them every batch
+    just to exchange <1 MB would re-introduce the tile-quantisation tails the streams exist to hide.  Instead:
+      * right after its NMS each sub-batch stream copies ITS rows into a staging slot (``stage``, pass it as
+        ``after_nms=`` of ``launch_detect``) and records an event — no cross-stream dependency;
+      * ``exchange()`` makes a dedicated side stream wait for those events and issues the two all-gathers there;
+        the compute streams never wait for it.
+    Two slots alternate, so batch i+1 stages while batch i is on the wire; a slot is rewritten only after its
+    previous exchange completed (an event the staging copy waits for — two batches later, never a stall in
+    practice).  ``exchange`` returns (all_dets, all_count, done_event); consume them after ``done_event``."""
+
+    def __init__(self, bs_local: int, cap: int, n_streams: int, device, group=None, gather_cap: int = 1024):
+        self.group, self.world = group, dist.get_world_size(group)
+        self.g = min(gather_cap, cap)
+        self.stream = torch.cuda.Stream(device=device)
+        self.slots = []
+        for _ in range(2):
+            self.slots.append(dict(
+                send=torch.zeros((bs_local, self.g, 7), dtype=torch.float32, device=device),
+                send_count=torch.zeros((bs_local,), dtype=torch.int32, device=device),
+                all_dets=torch.empty((self.world * bs_local, self.g, 7), dtype=torch.float32, device=device),
+                all_count=torch.empty((self.world * bs_local,), dtype=torch.int32, device=device),
+                staged=[torch.cuda.Event() for _ in range(n_streams)],
+                done=torch.cuda.Event(), used=False))
+        self._i = 0
+        self._nms_out = None
+
+    def begin(self, nms_out):
+        """Select the slot of the coming batch; ``nms_out`` = the (dets, idx, count) buffers NMS writes."""
+        self._slot = self.slots[self._i & 1]
+        self._i += 1
+        self._nms_out = nms_out
+        return self.stage
+
+    def stage(self, i: int, lo: int, hi: int):
+        """Runs in sub-batch stream i (its current stream) right after its NMS launch."""
+        sl = self._slot
+        st = torch.cuda.current_stream()
+        if sl["used"]:
+            st.wait_event(sl["done"])                      # the slot's previous exchange has left the buffers
+        sl["send"][lo:hi].copy_(self._nms_out[0][lo:hi, :self.g], non_blocking=True)
+        sl["send_count"][lo:hi].copy_(self._nms_out[2][lo:hi], non_blocking=True)
+        sl["staged"][i].record(st)
+
+    def exchange(self):
+        sl = self._slot
+        for ev in sl["staged"]:
+            self.stream.wait_event(ev)
+        with torch.cuda.stream(self.stream):
+            dist.all_gather_into_tensor(sl["all_count"], sl["send_count"], group=self.group)
+            dist.all_gather_into_tensor(sl["all_dets"], sl["send"], group=self.group)
+            sl["done"].record(self.stream)
+        sl["used"] = True
+        return sl["all_dets"], sl["all_count"], sl["done"]
+
+
 def split_gathered(all_dets, all_count) -> List[Optional[torch.Tensor]]:
     counts = all_count.cpu().tolist()
     g = all_dets.shape[1]

@@ -20,6 +20,7 @@ per head, optionally captured in a HIP graph.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional
 
@@ -27,7 +28,11 @@ import torch
 
 from . import kernels as K
 from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU6, DT_BF16, DT_F32, OP_CONV, OP_CONV1_NCHW, OP_DWCONV,
-                   OP_MAXPOOL, OP_SPP, YoloOp)
+                   OP_MAXPOOL, OP_RESUNIT, OP_SPP, YoloOp)
+
+# which residual-unit widths run as ONE launch (bit mask of C: 64 | 128 | 256); see DESIGN.md §3.1d for the
+# measurements behind the default.  YOLO_FUSE_RESUNIT overrides it (tuning only).
+FUSE_RESUNIT_DEFAULT = 64
 
 
 # ------------------------------------------------------------------------------------------------
@@ -201,9 +206,29 @@ class Plan:
                 if y.buf is None:
                     y.buf, y.c_offset = self._new_buf(y), 0
                 x.producer.attrs["up_into"] = y
+        # 2b. Darknet residual units (1x1 C->C/2, 3x3 C/2->C, add) on the large maps: one launch (yolo_resunit_fwd);
+        #     the intermediate never leaves the chip and the output gets its own buffer (no in-place add there)
+        fuse_mask = int(os.environ.get("YOLO_FUSE_RESUNIT", str(FUSE_RESUNIT_DEFAULT)))
+        for nd in nodes:
+            if nd.kind != "conv" or not nd.attrs["has_res"] or "up_into" in nd.attrs:
+                continue
+            mid, res = nd.srcs[0], nd.srcs[1]
+            pa = mid.producer
+            if pa is None or pa.kind != "conv" or pa.attrs["has_res"] or len(pa.outs) != 1 or len(mid.consumers) != 1:
+                continue
+            (w1, _), (w2, _) = pa.attrs["weight"], nd.attrs["weight"]
+            c = res.c
+            if (pa.srcs[0] is not res or w1.shape[2] != 1 or w2.shape[2] != 3 or nd.attrs["stride"] != 1
+                    or pa.attrs["stride"] != 1 or w2.shape[0] != c or w1.shape[0] * 2 != c or w1.shape[1] != c
+                    or pa.attrs["act"] != nd.attrs["act"] or "up_into" in pa.attrs or mid.buf is not None
+                    or nd.outs[0].f32):
+                continue
+            if (fuse_mask & c) and K.resunit_supported(c, res.h, res.w):
+                nd.attrs["fuse_pre"] = pa
+                pa.attrs["fused_away"] = True
         # 3. residual adds are written in place of the residual input when it is dead afterwards
         for nd in nodes:
-            if nd.kind == "conv" and nd.attrs["has_res"]:
+            if nd.kind == "conv" and nd.attrs["has_res"] and "fuse_pre" not in nd.attrs:
                 res, y = nd.srcs[1], nd.outs[0]
                 dead = all(order[id(cn)] <= order[id(nd)] for cn in res.consumers)
                 if dead and y.buf is None and res.buf is not None and not y.f32:
@@ -212,6 +237,8 @@ class Plan:
                     nd.attrs["alias_res"] = True
         # 4. everything else gets its own buffer
         for nd in nodes:
+            if nd.attrs.get("fused_away"):
+                continue
             for o in nd.outs:
                 if o.buf is None and not (nd.kind == "conv" and "up_into" in nd.attrs and o.slot == 0):
                     if nd.kind == "conv" and nd.attrs.get("alias_res") and o.slot == 0:
@@ -255,7 +282,27 @@ class Plan:
     def _build_ops(self):
         ops = []
         for nd in self.rec.nodes:
-            if nd.kind == "conv":
+            if nd.attrs.get("fused_away"):
+                continue
+            if nd.kind == "conv" and "fuse_pre" in nd.attrs:
+                pa = nd.attrs["fuse_pre"]
+                x, y, mid = nd.srcs[1], nd.outs[0], nd.srcs[0]
+                aux = nd.outs[1] if len(nd.outs) > 1 else None
+                w1p, b1p, kpad1, cout_pad1 = K.pack_conv_weight(*pa.attrs["weight"], x.c)
+                w2p, b2p, kpad2, cout_pad2 = K.pack_conv_weight(*nd.attrs["weight"], mid.c)
+                w1p, b1p, w2p, b2p = (self._dev(t) for t in (w1p, b1p, w2p, b2p))
+                op = YoloOp()
+                op.kind = OP_RESUNIT
+                op.x, op.y = x.buf.tensor.data_ptr(), y.buf.tensor.data_ptr()
+                op.w, op.bias, op.w_pre, op.bias_pre = w2p.data_ptr(), b2p.data_ptr(), w1p.data_ptr(), b1p.data_ptr()
+                op.kpad_pre, op.cout_pad_pre = kpad1, cout_pad1
+                op.y_aux = aux.buf.tensor.data_ptr() if aux is not None else None
+                op.conv = K.conv_desc(n=x.n, h=x.h, w=x.w, cin=mid.c, in_c_total=x.buf.c_total, in_c_offset=x.c_offset,
+                                      cout=x.c, out_c_total=y.buf.c_total, out_c_offset=y.c_offset, ksize=3, stride=1,
+                                      act=_ACT[nd.attrs["act"]], kpad=kpad2, cout_pad=cout_pad2,
+                                      aux=(aux.buf.c_total, aux.c_offset) if aux is not None else (0, 0))
+                ops.append(op)
+            elif nd.kind == "conv":
                 x = nd.srcs[0]
                 y = nd.outs[0]
                 w, b = nd.attrs["weight"]
@@ -356,13 +403,16 @@ class Plan:
             s = hd["sym"]
             K.decode(s.buf.tensor, hd["anchors"], self.n_class, hd["stride"], io, hd["row"], p)
 
-    def launch_detect(self, x, io, ps, nms_out, conf_thres, nms_thres, timing=None, join=True):
+    def launch_detect(self, x, io, ps, nms_out, conf_thres, nms_thres, timing=None, join=True, after_nms=None):
         """forward + decode + MERGE-NMS into caller-provided buffers; no host sync.
         nms_out = (dets [bs,cap,7] f32, idx [bs,cap] i32, count [bs] i32).  ``timing``: one (start, end)
-        event pair per stream, recorded around the conv launch list."""
+        event pair per stream, recorded around the conv launch list.  ``after_nms(i, lo, hi)`` is called in
+        the context of stream i right after the NMS launch of images [lo, hi) (see distributed.PipelinedGather)."""
         from .utils.utils import nms_launch
         self._launch(x, io, ps, timing=timing[0] if timing else None)
         nms_launch(io, conf_thres, nms_thres, nms_out, slot=0)
+        if after_nms is not None:
+            after_nms(0, 0, x.shape[0])
 
     n_streams = 1
 
@@ -377,6 +427,8 @@ class Plan:
                 cin = self.rec.c_in if first else d.cin      # the first layer's 3 -> 8 channel pad is not work
                 first = False
                 total += 2.0 * d.n * d.ho * d.wo * d.cout * d.ksize * d.ksize * cin
+            elif op.kind == OP_RESUNIT:                      # 1x1 C->C/2 plus 3x3 C/2->C (the halo recompute is not work)
+                total += 2.0 * d.n * d.h * d.w * (d.cout * d.cin) * 10
             elif op.kind == OP_DWCONV:
                 total += 2.0 * d.n * d.ho * d.wo * d.cin * 9
         return total
@@ -476,7 +528,7 @@ class StreamedPlan:
     def n_streams(self):
         return len(self.streams)
 
-    def launch_detect(self, x, io, ps, nms_out, conf_thres, nms_thres, timing=None, join=True):
+    def launch_detect(self, x, io, ps, nms_out, conf_thres, nms_thres, timing=None, join=True, after_nms=None):
         """Each stream runs the WHOLE pipeline (pack/conv1 -> layers -> decode -> NMS) of its sub-batch into
         slices of the shared buffers.  With ``join=False`` the calling stream neither waits for the previous
         work nor for this one: successive calls then form S free-running pipelines (in-order per stream, so
@@ -490,6 +542,8 @@ class StreamedPlan:
             with torch.cuda.stream(st):
                 pl._launch(x[lo:hi], io[lo:hi], tuple(p[lo:hi] for p in ps), timing=timing[i] if timing else None)
                 nms_launch(io[lo:hi], conf_thres, nms_thres, tuple(t[lo:hi] for t in nms_out), slot=i)
+                if after_nms is not None:
+                    after_nms(i, lo, hi)
         if join:
             for st in self.streams:
                 cur.wait_stream(st)

@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU6, DT_BF16, DT_F32, YoloConvDesc,
                    check, load)
 
-__all__ = ["stream_ptr", "pack_input", "conv2d", "maxpool", "spp", "dwconv3x3", "decode",
+__all__ = ["stream_ptr", "pack_input", "conv2d", "resunit", "resunit_supported", "maxpool", "spp", "dwconv3x3", "decode",
            "nms_merge", "pack_conv_weight", "roundup", "run_ops"]
 
 
@@ -80,6 +80,18 @@ def conv2d(x, w_packed, bias, y, desc: YoloConvDesc, residual=None, y_preadd=Non
     _need_cuda(x, w_packed, bias, y, residual, y_preadd)
     check(load().yolo_conv2d_fwd(_ptr(x), _ptr(w_packed), _ptr(bias), _ptr(residual), _ptr(y), _ptr(y_preadd),
                                  C.byref(desc), stream_ptr()), "conv2d")
+    return y
+
+
+def resunit_supported(c: int, h: int, w: int) -> bool:
+    return bool(load().yolo_resunit_supported(c, h, w))
+
+
+def resunit(x, w1_packed, b1, w2_packed, b2, y, desc: YoloConvDesc, kpad1: int, cout_pad1: int, y_preadd=None):
+    """One Darknet residual unit: y = x + act(conv3x3(act(conv1x1(x)))) (yolo_resunit_fwd); ``desc`` is the 3x3's."""
+    _need_cuda(x, w1_packed, b1, w2_packed, b2, y, y_preadd)
+    check(load().yolo_resunit_fwd(_ptr(x), _ptr(w1_packed), _ptr(b1), _ptr(w2_packed), _ptr(b2), _ptr(y), _ptr(y_preadd),
+                                  C.byref(desc), kpad1, cout_pad1, stream_ptr()), "resunit")
     return y
 
 

@@ -119,6 +119,56 @@ def test_conv_kernel(case):
         assert torch.all(aux[..., :8] == -77.0)
 
 
+@pytest.mark.parametrize("n,h,w,c,use_aux", [(1, 80, 80, 256, False), (2, 96, 80, 128, True), (1, 94, 100, 64, False),
+                                              (2, 80, 112, 256, True)])
+def test_fused_residual_unit(n, h, w, c, use_aux):
+    """yolo_resunit_fwd (1x1 -> 3x3 -> add in one launch) against fp32 torch on the same bf16-rounded operands
+    (the 1x1 output rounded to bf16 like the stored intermediate of the two-kernel path), and against the
+    two-kernel path itself; partial edge tiles, channel-offset views and the pre-add copy are exercised."""
+    from pytorch_yolo_amd import kernels as K
+    from pytorch_yolo_amd._lib import ACT_LEAKY01
+    assert K.resunit_supported(c, h, w)
+    g = torch.Generator().manual_seed(c + h)
+    x = torch.randn(n, c, h, w, generator=g)
+    w1 = torch.randn(c // 2, c, 1, 1, generator=g) * (2.0 / c) ** 0.5
+    b1 = torch.randn(c // 2, generator=g) * 0.1
+    w2 = torch.randn(c, c // 2, 3, 3, generator=g) * (2.0 / (c // 2 * 9)) ** 0.5
+    b2 = torch.randn(c, generator=g) * 0.1
+    in_ct, in_co, out_ct, out_co = c + 16, 8, c + 8, 8
+    xin = torch.zeros(n, h, w, in_ct, dtype=torch.bfloat16, device=DEV)
+    xin[..., in_co:in_co + c] = _nhwc(x)
+    y = torch.full((n, h, w, out_ct), -77.0, dtype=torch.bfloat16, device=DEV)
+    aux = torch.full((n, h, w, c + 8), -77.0, dtype=torch.bfloat16, device=DEV) if use_aux else None
+    w1p, b1p, kpad1, cpad1 = K.pack_conv_weight(w1, b1, c)
+    w2p, b2p, kpad2, cpad2 = K.pack_conv_weight(w2, b2, c // 2)
+    d = K.conv_desc(n=n, h=h, w=w, cin=c // 2, in_c_total=in_ct, in_c_offset=in_co, cout=c, out_c_total=out_ct,
+                    out_c_offset=out_co, ksize=3, stride=1, act=ACT_LEAKY01, kpad=kpad2, cout_pad=cpad2,
+                    aux=(c + 8, 8) if use_aux else (0, 0))
+    K.resunit(xin, w1p.to(DEV), b1p.to(DEV), w2p.to(DEV), b2p.to(DEV), y, d, kpad1, cpad1, y_preadd=aux)
+    torch.cuda.synchronize()
+    mid = _bf16r(F.leaky_relu(F.conv2d(_bf16r(x), _bf16r(w1), b1), 0.1))
+    pre = F.leaky_relu(F.conv2d(mid, _bf16r(w2), b2, padding=1), 0.1)
+    ref = pre + _bf16r(x)
+    got = _nchw(y[..., out_co:])
+    torch.testing.assert_close(got, ref, rtol=1e-2, atol=2e-2)
+    assert torch.all(y[..., :out_co] == -77.0)
+    if use_aux:
+        torch.testing.assert_close(_nchw(aux[..., 8:]), pre, rtol=1e-2, atol=2e-2)
+        assert torch.all(aux[..., :8] == -77.0)
+    # two-kernel path on the same operands: differences only from fp32 summation order (<= 1 bf16 ulp of a few values)
+    midb = torch.empty(n, h, w, c // 2, dtype=torch.bfloat16, device=DEV)
+    d1 = K.conv_desc(n=n, h=h, w=w, cin=c, in_c_total=in_ct, in_c_offset=in_co, cout=c // 2, out_c_total=c // 2,
+                     out_c_offset=0, ksize=1, stride=1, act=ACT_LEAKY01, kpad=kpad1, cout_pad=cpad1)
+    K.conv2d(xin, w1p.to(DEV), b1p.to(DEV), midb, d1)
+    y2 = torch.empty(n, h, w, c, dtype=torch.bfloat16, device=DEV)
+    d2 = K.conv_desc(n=n, h=h, w=w, cin=c // 2, in_c_total=c // 2, in_c_offset=0, cout=c, out_c_total=c, out_c_offset=0,
+                     ksize=3, stride=1, act=ACT_LEAKY01, kpad=kpad2, cout_pad=cpad2, res=(in_ct, in_co))
+    K.conv2d(midb, w2p.to(DEV), b2p.to(DEV), y2, d2, residual=xin)
+    torch.cuda.synchronize()
+    diff = (y[..., out_co:].float() - y2.float()).abs()
+    assert float(diff.max()) <= 0.07 and float((diff > 0).float().mean()) < 0.25, (float(diff.max()), float((diff > 0).float().mean()))
+
+
 @pytest.mark.parametrize("cin,h,w", [(3, 37, 50), (3, 64, 64), (1, 20, 33), (8, 16, 16)])
 def test_first_layer_fused_with_input_packing(cin, h, w):
     """yolo_conv1_nchw_f32_fwd: the first ConvBlock reads the float32 NCHW batch directly (no packed copy)."""
@@ -429,3 +479,57 @@ def test_cpu_input_fails_loudly():
     model.train()
     with pytest.raises(NotImplementedError):
         model(x.to(DEV))
+
+
+def test_pipelined_gather_matches_joined_gather():
+    """distributed.PipelinedGather (side-stream all-gather of free-running sub-batch pipelines) returns what the
+    joined gather_detections returns, batch after batch, and detect results stay those of a joined run.
+    One rank over RCCL here (the GPU box has one card); the world_size-2 exchange itself is covered on gloo."""
+    import torch.distributed as dist
+    from pytorch_yolo_amd.distributed import PipelinedGather, gather_detections
+    from pytorch_yolo_amd.utils.synthetic import synth_images
+    from pytorch_yolo_amd.utils.utils import nms_capacity
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1,
+                                device_id=torch.device(DEV))
+    try:
+        case = C.MODEL_CASES["spp_small"]
+        model, sd, _ = build_case(case)
+        model = model.to(DEV)
+        model.n_streams = 2
+        bs = 8
+        xs = [synth_images(bs, 64, 64, 10 + k).to(DEV) for k in range(4)]
+        plan = model.plan_for(xs[0])
+        assert type(plan).__name__ == "StreamedPlan"
+        cap = nms_capacity(plan.rows_total, model.n_class)
+        mk = lambda: (torch.zeros((bs, cap, 7), device=DEV), torch.zeros((bs, cap), dtype=torch.int32, device=DEV),
+                      torch.zeros((bs,), dtype=torch.int32, device=DEV))
+        io, ps = plan.new_outputs()
+        # joined reference, one batch at a time
+        want = []
+        for x in xs:
+            out = mk()
+            plan.launch_detect(x, io, ps, out, 1e-4, 0.5, join=True)
+            torch.cuda.synchronize()
+            d, c = gather_detections(out[0], out[2])
+            torch.cuda.synchronize()
+            want.append((d.clone(), c.clone()))
+        # free-running pipelines + side-stream exchange, no sync until the end
+        g = PipelinedGather(bs, cap, plan.n_streams, torch.device(DEV))
+        out = mk()
+        got = []
+        for x in xs:
+            plan.launch_detect(x, io, ps, out, 1e-4, 0.5, join=False, after_nms=g.begin(out))
+            d, c, done = g.exchange()
+            done.synchronize()                # results of this batch are complete here (slots alternate)
+            got.append((d.clone(), c.clone()))
+        torch.cuda.synchronize()
+        assert sum(int(c.sum()) for _, c in want) > 0
+        for (dw, cw), (dg, cg) in zip(want, got):
+            assert torch.equal(cw, cg)
+            for b, n in enumerate(cw.tolist()):
+                assert torch.equal(dw[b, :n], dg[b, :n])
+    finally:
+        if created:
+            dist.destroy_process_group()

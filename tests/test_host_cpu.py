@@ -13,7 +13,7 @@ import torch
 import _cases as C
 from pytorch_yolo_amd import YOLOv3SPP, YOLOv3Tiny, YOLOv3TinyMobile, _lib, engine
 from pytorch_yolo_amd import kernels as K
-from pytorch_yolo_amd._lib import OP_CONV, OP_CONV1_NCHW, OP_DWCONV, OP_MAXPOOL, OP_SPP
+from pytorch_yolo_amd._lib import OP_CONV, OP_CONV1_NCHW, OP_RESUNIT, OP_DWCONV, OP_MAXPOOL, OP_SPP
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -34,9 +34,10 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layout_matches_header():
-    # 23 int32 fields in YoloConvDesc; YoloOp = 2 int32 + 6 pointers + desc
+    # 23 int32 fields in YoloConvDesc; YoloOp = 2 int32 + 6 pointers + desc (+4 pad) + 2 pointers + 2 int32
     assert ctypes.sizeof(_lib.YoloConvDesc) == 23 * 4
-    assert ctypes.sizeof(_lib.YoloOp) == 8 + 6 * 8 + 23 * 4 + 4   # tail padding to 8-byte alignment
+    assert ctypes.sizeof(_lib.YoloOp) == 8 + 6 * 8 + 23 * 4 + 4 + 2 * 8 + 2 * 4
+    assert _lib.YoloOp.w_pre.offset == 152 and _lib.YoloOp.kpad_pre.offset == 168
     text = open(os.path.join(ROOT, "include", "yolo_hip.h")).read()
     body = text[text.index("typedef struct YoloConvDesc {"):text.index("} YoloConvDesc;")]
     fields = re.findall(r"\b([a-z_0-9]+)\s*[,;]", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
@@ -106,9 +107,12 @@ def test_planner_spp_fusions():
     ops = _ops(plan)
     kinds = [o.kind for o in ops]
     assert ops[0].kind == OP_CONV1_NCHW and plan.fused_input                              # first layer reads the NCHW f32 batch itself
-    assert kinds.count(OP_CONV) == 75 and kinds.count(OP_SPP) == 1 and len(ops) == 77      # no add / cat / upsample / pack launches
+    # no add / cat / upsample / pack launches; the 64-channel residual unit at 320^2 is ONE launch (yolo_resunit_fwd)
+    assert kinds.count(OP_CONV) == 73 and kinds.count(OP_RESUNIT) == 1 and kinds.count(OP_SPP) == 1 and len(ops) == 76
+    unit = ops[kinds.index(OP_RESUNIT)]
+    assert (unit.conv.cout, unit.conv.cin, unit.conv.h) == (64, 32, 320) and unit.y != unit.x and unit.w_pre and unit.bias_pre
     convs = [o for o in ops if o.kind == OP_CONV]
-    assert sum(1 for o in convs if o.residual) == 23                                        # every Add is an epilogue
+    assert sum(1 for o in convs if o.residual) == 22                                        # every other Add is an epilogue
     assert all(o.residual == o.y for o in convs if o.residual)                              # ... written in place
     aux = [o for o in convs if o.y_aux]
     assert [(o.conv.aux_c_total, o.conv.aux_c_offset) for o in aux] == [(384, 128), (768, 256)]   # pre-add routes -> concat slices

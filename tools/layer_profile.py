@@ -19,7 +19,7 @@ spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench
 bench = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(bench)
 from pytorch_yolo_amd import kernels as K
-from pytorch_yolo_amd._lib import OP_CONV, OP_CONV1_NCHW, OP_DWCONV, OP_MAXPOOL, OP_SPP, YoloOp
+from pytorch_yolo_amd._lib import OP_CONV, OP_CONV1_NCHW, OP_DWCONV, OP_MAXPOOL, OP_RESUNIT, OP_SPP, YoloOp
 from pytorch_yolo_amd.utils.synthetic import synth_images, synth_state_dict
 
 
@@ -69,6 +69,12 @@ def main():
             tot_fl += fl
             flags = ("res " if op.residual else "") + ("aux " if op.y_aux else "") + ("up " if d.upsample2x else "") + ("f32" if d.out_dtype else "")
             print(f"{i:3d} {'conv':7} {M:9d} {N:5d} {Kd:5d} {d.ksize:1d} {d.stride:1d} {ms:8.4f} {fl / ms / 1e9:8.1f} {by / ms / 1e6:7.0f}  {flags}")
+        elif op.kind == OP_RESUNIT:
+            M, Cc = d.n * d.h * d.w, d.cout
+            fl = 2.0 * M * (Cc * Cc // 2) * 10
+            tot_fl += fl
+            by = M * Cc * 2 * 3
+            print(f"{i:3d} {'resunit':7} {M:9d} {Cc:5d} {Cc * 5:5d} 3 1 {ms:8.4f} {fl / ms / 1e9:8.1f} {by / ms / 1e6:7.0f}  {'aux' if op.y_aux else ''}")
         else:
             kind = {OP_MAXPOOL: "pool", OP_SPP: "spp", OP_DWCONV: "dwconv"}[op.kind]
             by = d.n * d.h * d.w * d.cin * 2 * (4 if op.kind == OP_SPP else 2)
