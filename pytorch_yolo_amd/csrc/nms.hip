@@ -57,15 +57,29 @@ __global__ __launch_bounds__(256) void nms_filter_kernel(float* __restrict__ pre
   const int nrows = min(kFilterRows, rows - r0);
   float* src = pred + ((long)b * rows + r0) * no;
   const int nflt = nrows * no;
-  for (int i = threadIdx.x; i < nflt; i += 256) tile[i] = src[i];
+  if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {       // whole tiles of 16-byte aligned rows: 16 B per lane
+    const int n4 = nflt >> 2;
+    const float4* src4 = reinterpret_cast<const float4*>(src);
+    float4* tile4 = reinterpret_cast<float4*>(tile);
+    for (int i = threadIdx.x; i < n4; i += 256) tile4[i] = src4[i];
+    for (int i = (n4 << 2) + threadIdx.x; i < nflt; i += 256) tile[i] = src[i];
+  } else {
+    for (int i = threadIdx.x; i < nflt; i += 256) tile[i] = src[i];
+  }
   __syncthreads();
-  if ((int)threadIdx.x >= nrows) return;
-  const float* row = tile + threadIdx.x * no;
-  // class max / argmax: first maximum wins, a NaN poisons the result (torch.max semantics)
-  float best = row[5];
-  int arg = 0;
-  bool all_finite = finite_f(best);
-  for (int k = 1; k < no - 5; ++k) {
+  // four lanes per row, each scanning a quarter of the classes in order; the quarters are then merged in order,
+  // which reproduces the sequential scan exactly: first maximum wins, the first NaN poisons the result
+  // (torch.max semantics, utils.py:212)
+  const int rloc = threadIdx.x >> 2, seg = threadIdx.x & 3;
+  const int nc = no - 5, cps = (nc + 3) >> 2;
+  const int k0 = seg * cps, k1 = min(nc, k0 + cps);
+  const bool live = rloc < nrows;
+  const float* row = tile + (live ? rloc : 0) * no;
+  bool have = k0 < k1;
+  float best = have ? row[5 + k0] : 0.f;
+  int arg = k0;
+  bool all_finite = !have || finite_f(best);
+  for (int k = k0 + 1; k < k1; ++k) {
     const float v = row[5 + k];
     all_finite = all_finite && finite_f(v);
     if (v > best || (v != v && best == best)) {
@@ -73,14 +87,32 @@ __global__ __launch_bounds__(256) void nms_filter_kernel(float* __restrict__ pre
       arg = k;
     }
   }
+#pragma unroll
+  for (int m = 1; m <= 2; m <<= 1) {
+    const float ob = __shfl_xor(best, m);
+    const int oa = __shfl_xor(arg, m);
+    const bool oh = __shfl_xor((int)have, m) != 0;
+    const bool of = __shfl_xor((int)all_finite, m) != 0;
+    const bool other_is_right = (seg & m) == 0;
+    // (lb, la) = the earlier quarter(s), (rb, ra) = the later ones
+    const float lb = other_is_right ? best : ob, rb = other_is_right ? ob : best;
+    const int la = other_is_right ? arg : oa, ra = other_is_right ? oa : arg;
+    const bool lh = other_is_right ? have : oh, rh = other_is_right ? oh : have;
+    const bool take_r = rh && (!lh || rb > lb || (rb != rb && lb == lb));
+    best = take_r ? rb : lb;
+    arg = take_r ? ra : la;
+    have = lh || rh;
+    all_finite = all_finite && of;
+  }
+  if (!live || seg != 0) return;
   const float conf = row[4] * best;                                              // utils.py:213
-  if (mutate) src[threadIdx.x * no + 4] = conf;
+  if (mutate) src[rloc * no + 4] = conf;
   const float bw = row[2], bh = row[3];
   all_finite = all_finite && finite_f(row[0]) && finite_f(row[1]) && finite_f(bw) && finite_f(bh) && finite_f(conf);
   const bool keep = (conf > conf_thres) && (bw > min_wh) && (bh > min_wh) && all_finite;  // :216-218
   if (keep) {
     const int pos = atomicAdd(&counts[b], 1);
-    keys[(long)b * key_pitch + pos] = make_key(arg, conf, r0 + threadIdx.x);
+    keys[(long)b * key_pitch + pos] = make_key(arg, conf, r0 + rloc);
   }
 }
 
