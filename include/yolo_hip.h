@@ -114,6 +114,15 @@ YOLO_API int yolo_resunit_fwd(const void* x, const void* w1_packed, const float*
                               const float* b2, void* y, void* y_preadd, const YoloConvDesc* d, int kpad1,
                               int cout_pad1, yolo_stream_t s);
 
+/* ---- the Darknet stem in one launch (models/yolov3_spp.py:98 ConvBlock 3x3/s1 cin->32, then DownSample's
+ *  ConvBlock 3x3/s2 32->64, :26-27):  y = act(conv_s2(act(conv_s1(x,W1)+b1), W2)+b2), x = float32 NCHW
+ *  [n,cin_real,h,w] (1..8 channels), y = bf16 NHWC view at h/2 x w/2.  The 32-channel intermediate (the
+ *  largest activation of the network) stays in LDS.  d describes the stride-2 conv (h,w = input size,
+ *  cin 32, cout 64, kpad = packing of W2); W1 is packed as for yolo_conv1_nchw_f32_fwd (cin = 8, kpad1 >= 80). */
+YOLO_API int yolo_stem_supported(int cin_real, int c1, int c2, int h, int w);
+YOLO_API int yolo_stem_fwd(const float* x_nchw, int cin_real, const void* w1_packed, const float* b1, int kpad1,
+                           const void* w2_packed, const float* b2, void* y, const YoloConvDesc* d, yolo_stream_t s);
+
 /* ---- YOLOLayer.forward eval branch (models/yolo_layer.py:57-69,90-111).
  *  head: f32 NHWC [bs,ny,nx,head_c_total], channel a*(5+nc)+k.
  *  io:   f32 [bs, io_rows_total, 5+nc]; this head fills rows [io_row_offset, +na*ny*nx).
@@ -143,15 +152,17 @@ YOLO_API int yolo_scale_coords(float* dets, int bs, int cap, int row_floats, con
 
 /* ---- batched launcher: run a recorded list of ops with one FFI crossing (host overhead only). */
 enum { YOLO_OP_CONV = 1, YOLO_OP_MAXPOOL = 2, YOLO_OP_SPP = 3, YOLO_OP_DWCONV = 4, YOLO_OP_CONV1_NCHW = 5,
-       YOLO_OP_RESUNIT = 6 };
+       YOLO_OP_RESUNIT = 6, YOLO_OP_STEM = 7 };
 typedef struct YoloOp {
   int32_t kind, _pad;
   const void* x; const void* w; const float* bias; const void* residual; void* y; void* y_aux;
   YoloConvDesc conv;             /* kind CONV; DWCONV/MAXPOOL/SPP reuse the geometry fields
                                     (ksize/stride/pad, act, views); MAXPOOL dilation = upsample2x field;
                                     CONV1_NCHW: x = f32 NCHW input, res_c_total = real input channels;
-                                    RESUNIT: the unit's 3x3 (w/bias = W2/b2), see yolo_resunit_fwd */
-  const void* w_pre; const float* bias_pre;   /* RESUNIT: packed W1 / b1 of the leading 1x1 */
+                                    RESUNIT: the unit's 3x3 (w/bias = W2/b2), see yolo_resunit_fwd;
+                                    STEM: the stride-2 conv (w/bias = W2/b2), x = f32 NCHW input,
+                                    res_c_total = real input channels, see yolo_stem_fwd */
+  const void* w_pre; const float* bias_pre;   /* RESUNIT / STEM: packed W1 / b1 of the leading conv */
   int32_t kpad_pre, cout_pad_pre;
 } YoloOp;
 YOLO_API int yolo_run_ops(const YoloOp* ops, int n_ops, yolo_stream_t s);

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libyolo_hip.so")
 
 ACT_NONE, ACT_LEAKY01, ACT_RELU6 = 0, 1, 2
 DT_BF16, DT_F32 = 0, 1
-OP_CONV, OP_MAXPOOL, OP_SPP, OP_DWCONV, OP_CONV1_NCHW, OP_RESUNIT = 1, 2, 3, 4, 5, 6
+OP_CONV, OP_MAXPOOL, OP_SPP, OP_DWCONV, OP_CONV1_NCHW, OP_RESUNIT, OP_STEM = 1, 2, 3, 4, 5, 6, 7
 
 
 class YoloConvDesc(C.Structure):
@@ -41,6 +41,9 @@ SIGNATURES = {
     "yolo_conv1_nchw_f32_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.POINTER(YoloConvDesc), C.c_void_p]),
     "yolo_pack_conv_weight_f32": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
+    "yolo_stem_supported": (C.c_int, [C.c_int] * 5),
+    "yolo_stem_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.POINTER(YoloConvDesc), C.c_void_p]),
     "yolo_resunit_supported": (C.c_int, [C.c_int] * 3),
     "yolo_resunit_fwd": (C.c_int, [C.c_void_p] * 7 + [C.POINTER(YoloConvDesc), C.c_int, C.c_int, C.c_void_p]),
     "yolo_dwconv3x3_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 12 + [C.c_void_p]),

@@ -20,6 +20,7 @@ SOURCES = {
     "conv_igemm.hip": [],
     "conv3x3_halo.hip": [],
     "conv_resunit.hip": [],
+    "conv_stem.hip": [],
     "pointwise.hip": [],
     "nms.hip": ["-ffp-contract=off"],
 }

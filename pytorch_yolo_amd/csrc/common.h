@@ -33,6 +33,16 @@ static inline int yolo_check_launch(const char* what) {
 // bf16 <-> f32 bit helpers (device).  Widening is exact; narrowing uses the hardware RNE cast.
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t hi16) { return __uint_as_float(hi16 << 16); }
 
+// One element of the YOLOLayer decode (reference models/yolo_layer.py:90-96): raw head value r of role k
+// (0,1 = x,y; 2,3 = w,h; 4 = objectness; 5.. = classes) at grid cell (gx, gy); anchor = anchor_px / stride for
+// this role.  Shared by the standalone decode kernel and the head-conv epilogue so that both give the same bits.
+__device__ __forceinline__ float yolo_decode_elem(float r, int k, int gx, int gy, float anchor, float stride, int nc) {
+  if (k < 2) return (1.f / (1.f + expf(-r)) + (float)(k == 0 ? gx : gy)) * stride;   // :91,:94
+  if (k < 4) return (expf(r) * anchor) * stride;                                      // :92,:94
+  if (nc == 1 && k == 5) return 1.f;                                                  // :95-96
+  return 1.f / (1.f + expf(-r));                                                      // :93
+}
+
 // per-op launch entry points shared with the batched launcher
 int yolo_conv2d_launch(const void* x, const void* w, const float* bias, const void* res, void* y, void* y_aux,
                        const YoloConvDesc* d, hipStream_t s);

@@ -6,6 +6,15 @@ namespace yolo_conv {
 
 constexpr uint32_t kOobOffset = 0xF0000000u;  // > any buffer we accept (host checks < 0xF0000000 bytes)
 
+// YOLOLayer decode fused into a head conv's epilogue (conv_igemm.hip, DECODE instances)
+struct HeadDecodeArgs {
+  float* io;            // [bs, io_rows_total, no]
+  float* p;             // [bs, na, ny, nx, no] or null
+  int na, no, io_rows_total, io_row_offset;
+  float stride;
+  float anchor_w[4], anchor_h[4];   // anchors_px / stride (yolo_layer.py:109)
+};
+
 struct ConvArgs {
   const bf16_t* x;
   const bf16_t* w;
@@ -18,6 +27,7 @@ struct ConvArgs {
   int n_tiles;  // cout tiles
   int steps;    // kpad / 32
   uint32_t x_bytes, w_bytes;
+  HeadDecodeArgs hd;   // DECODE instances only
   int debug;    // timing ablations only (YOLO_CONV_DEBUG): 1 no pixel DMA, 2 no weight DMA, 4 no MFMA, 8 no epilogue
 };
 

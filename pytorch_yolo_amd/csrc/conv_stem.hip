@@ -1,0 +1,297 @@
+// Fused Darknet stem for gfx950 (MI355X): the first two ConvBlocks of the YOLOv3 encoders in one launch
+//     mid = act(conv3x3/s1(x, W1) + b1)          3 -> 32 channels at H x W        (models/yolov3_spp.py:98)
+//     y   = act(conv3x3/s2(mid, W2) + b2)        32 -> 64 channels at H/2 x W/2   (DownSample conv0, :26-27)
+// x is the caller's float32 NCHW batch (reference input contract utils/dataset_csv.py:79-87).
+//
+// Why: both layers are HBM-bound, and between them sits the largest activation of the network
+// (H*W*32 bf16 = 26 MB per 640^2 image): written once, read 2.25x (stride-2 taps) through L2.  Run
+// separately they cost 0.14 + 0.24 ms per 16 images; their algorithmic traffic WITHOUT the intermediate
+// (read x, write y) is a quarter of what they move.  Here a block owns a 16 x 16 tile of y:
+//   stage   the 35 x 35 input halo: NCHW f32 -> registers (prefetched one tile ahead) -> LDS as NHWC8 bf16;
+//   phase A mid on the 33 x 33 halo (6 % recompute) by MFMA, K = 10 taps x 8 channels with the weight
+//           fragments in registers (as conv1_nchw_kernel), the bias as the accumulators' initial value, act,
+//           rounded to bf16 once (as the two-kernel path rounds what it stores) into LDS.  Pixels outside the image are ZERO (the second
+//           conv zero-pads `mid`).  Columns are split by parity into two planes so that the stride-2 taps
+//           of phase B read consecutive 64-byte rows (XOR-swizzled, conflict-free);
+//   phase B the nine taps of the stride-2 conv read `mid` from LDS; W2 (64 x 288, 37 KB) sits in LDS for
+//           the whole block;
+//   store   bias + act -> bf16 -> LDS staging -> 16 B per lane, 128 contiguous bytes per pixel.
+// One persistent block per CU walks its share of the tile list, so W2 / W1 / biases are loaded once per CU.
+#include "conv_common.h"
+
+using namespace yolo_conv;
+
+namespace {
+
+struct StemArgs {
+  const float* x;       // [n, cin_real, h, w] f32
+  const bf16_t* w1;     // packed [>=32][kpad1 >= 80], k = tap*8 + c
+  const float* b1;
+  const bf16_t* w2;     // packed [>=64][kpad2 >= 288], k = tap*32 + c
+  const float* b2;
+  bf16_t* y;            // NHWC view
+  int n, h, w, cin_real, ho, wo, out_c_total, out_c_offset, kpad1, kpad2, act;
+  int debug;            // timing ablations (YOLO_STEM_DEBUG): 1 no input loads, 2 no phase A, 4 no phase B, 8 no stores
+};
+
+template <bool LEAKY>
+__global__ __launch_bounds__(512) void stem_kernel(const StemArgs a) {
+  constexpr int NW = 8;
+  constexpr int IW = 35, IP = IW * IW;                 // input halo (pixels)
+  constexpr int MW = 33, MP = MW * MW;                 // mid halo
+  constexpr int EV_COLS = 17, OD_COLS = 16;            // parity planes of mid: even / odd columns
+  constexpr int OD_BASE = MW * EV_COLS;                // first row of the odd plane
+  constexpr int MID_B = ((MP * 64 + 1023) / 1024) * 1024;
+  constexpr int W2_PITCH = 592;                        // 288 k * 2 B + 16 B: the 16 B-per-lane fragment reads spread over all banks
+  constexpr int W2_B = 64 * W2_PITCH;
+  constexpr int IN_B = ((IP * 16 + 1023) / 1024) * 1024;
+  constexpr int SP = 144;                              // output staging pitch: 64 couts bf16 + 16 B
+  constexpr int OUT_B = NW * 16 * SP;                  // staging: 16 pixels per wave at a time
+  constexpr int LDS_B = IN_B + OUT_B + MID_B + W2_B;
+  constexpr int A_BLOCKS = (MP + 31) / 32;             // 35 blocks of 32 mid pixels
+  static_assert(LDS_B <= 160 * 1024, "LDS");
+
+  __shared__ __attribute__((aligned(16))) char smem[LDS_B];
+  char* const s_in = smem;
+  char* const s_out = smem + IN_B;
+  char* const s_mid = smem + IN_B + OUT_B;
+  char* const s_w2 = smem + IN_B + OUT_B + MID_B;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r32 = lane & 31, khalf = lane >> 5;
+
+  // persistent blocks: block i owns the i-th of gridDim.x equal runs of the tile list (image, tile row, tile col),
+  // so the weights / biases / per-lane tables are set up once per CU and neighbouring halos come from L2
+  const int tiles_x = (a.wo + 15) / 16, tiles_y = (a.ho + 15) / 16;
+  const long total = (long)a.n * tiles_y * tiles_x;
+  const int lb = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int t_lo = (int)(lb * total / gridDim.x), t_hi = (int)((lb + 1) * total / gridDim.x);
+  if (t_lo >= t_hi) return;
+
+  // ---- block-constant operands: W2 -> LDS, W1 fragments and biases -> registers
+  u32x4 w2tmp[5];                                      // W2: 64 rows x 36 sixteen-byte pieces (288 k); stored to LDS below
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int i = tid + j * 512, row = i / 36, piece = i - row * 36;
+    if (i < 64 * 36) w2tmp[j] = *reinterpret_cast<const u32x4*>(a.w2 + (long)row * a.kpad2 + piece * 8);
+  }
+  bf16x8 wf1[5];
+#pragma unroll
+  for (int ks = 0; ks < 5; ++ks) wf1[ks] = *reinterpret_cast<const bf16x8*>(a.w1 + (long)r32 * a.kpad1 + ks * 16 + khalf * 8);
+  // biases enter as the accumulators' initial value (register e <-> cout (e&3) + 8*(e>>2) + 4*khalf)
+  f32x16 bias1, bias2[2];
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      bias1[g4 * 4 + e] = a.b1[g4 * 8 + khalf * 4 + e];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) bias2[i][g4 * 4 + e] = a.b2[i * 32 + g4 * 8 + khalf * 4 + e];
+    }
+  auto act = [&](float v) -> float { return LEAKY ? fmaxf(v, 0.1f * v) : apply_act(v, a.act); };
+
+  // phase A, per lane and per block slot s (mid pixel q = (wave + 8 s)*32 + r32): LDS offsets are tile-invariant
+  constexpr int A_SLOTS = (A_BLOCKS + NW - 1) / NW;    // 5
+  int a_rd[A_SLOTS], a_wr[A_SLOTS], a_pos[A_SLOTS];
+#pragma unroll
+  for (int sl = 0; sl < A_SLOTS; ++sl) {
+    const int q = (wave + NW * sl) * 32 + r32;
+    const bool valid = q < MP;
+    const int qq = valid ? q : 0;
+    const int my = qq / MW, mx = qq - my * MW;
+    const int R = (mx & 1) ? OD_BASE + my * OD_COLS + (mx >> 1) : my * EV_COLS + (mx >> 1);
+    a_rd[sl] = (my * IW + mx) * 16;
+    // row base has bits 4,5 clear, so the XOR swizzle of the 16-byte slot can be applied to the address itself
+    a_wr[sl] = valid ? ((R * 64 + khalf * 8) ^ (((R >> 2) & 3) << 4)) : -1;
+    a_pos[sl] = (my << 8) | mx;
+  }
+  int tapoff[5];
+#pragma unroll
+  for (int ks = 0; ks < 5; ++ks) {
+    int tap = ks * 2 + khalf;
+    if (tap > 8) tap = 8;                                 // tap 9 carries zero weights: read any valid pixel
+    const int dh = (tap * 11) >> 5, dw = tap - 3 * dh;
+    tapoff[ks] = (dh * IW + dw) * 16;
+  }
+
+  // ---- input halo pixels owned by this thread (3 of the 1225), prefetched one tile ahead into registers
+  const long plane = (long)a.h * a.w;
+  float pre[3][8];
+  auto fetch = [&](int t) {
+    const int tx = t % tiles_x, r = t / tiles_x;
+    const int ty = r % tiles_y, b = r / tiles_y;
+    const int iy0 = 2 * ty * 16 - 2, ix0 = 2 * tx * 16 - 2;     // halo origin in input coordinates
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int hp = tid + u * 512;
+      const int hy = hp / IW, hx = hp - hy * IW;
+      const int yy = iy0 + hy, xx = ix0 + hx;
+      const bool ok = hp < IP && (unsigned)yy < (unsigned)a.h && (unsigned)xx < (unsigned)a.w && !(a.debug & 1);
+      const float* src = a.x + ((long)b * a.cin_real) * plane + (long)yy * a.w + xx;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pre[u][e] = (ok && e < a.cin_real) ? src[e * plane] : 0.f;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int hp = tid + u * 512;
+      if (hp >= IP) continue;
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (bf16_t)pre[u][e];
+      *reinterpret_cast<bf16x8*>(s_in + hp * 16) = v;
+    }
+  };
+
+  // phase B fragment rows: output pixel q = wave*32 + r32 of the 16 x 16 tile
+  const int qy = (wave * 32 + r32) >> 4, qx = r32 & 15;
+
+  fetch(t_lo);
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {                        // issued before fetch(): landed by the time fetch's data is
+    const int i = tid + j * 512, row = i / 36, piece = i - row * 36;
+    if (i < 64 * 36) *reinterpret_cast<u32x4*>(s_w2 + row * W2_PITCH + piece * 16) = w2tmp[j];
+  }
+  for (int t = t_lo; t < t_hi; ++t) {
+    const int tx = t % tiles_x, tr = t / tiles_x;
+    const int ox0 = tx * 16, oy0 = (tr % tiles_y) * 16, b = tr / tiles_y;
+    commit();
+    __syncthreads();                       // input halo t (and, first time, W2) in LDS; every wave has left phase B of t-1
+    if (t + 1 < t_hi) fetch(t + 1);        // global loads fly during both MFMA phases
+
+    // ================= phase A: mid = act(conv3x3/s1(x) + b1) on the 33 x 33 halo -> LDS =================
+    // tiles whose whole 33 x 33 halo lies inside the image (all but the border tiles) need no per-pixel test
+    const bool interior = 2 * oy0 - 1 >= 0 && 2 * oy0 + 31 < a.h && 2 * ox0 - 1 >= 0 && 2 * ox0 + 31 < a.w;
+#pragma unroll
+    for (int sl = 0; sl < A_SLOTS; ++sl) {
+      if (wave + NW * sl >= A_BLOCKS || (a.debug & 2)) break;
+      f32x16 acc = bias1;
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) {
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(s_in + a_rd[sl] + tapoff[ks]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1[ks], xf, acc, 0, 0, 0);
+      }
+      if (a_wr[sl] >= 0) {
+        bool inside = true;
+        if (!interior) {
+          const int gy = 2 * oy0 - 1 + (a_pos[sl] >> 8), gx = 2 * ox0 - 1 + (a_pos[sl] & 255);   // position in the H x W map
+          inside = (unsigned)gy < (unsigned)a.h && (unsigned)gx < (unsigned)a.w;
+        }
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (bf16_t)act(acc[g4 * 4 + e]);
+          u32x2 bits = __builtin_bit_cast(u32x2, o);
+          if (!inside) bits = u32x2{0u, 0u};
+          *reinterpret_cast<u32x2*>(s_mid + (a_wr[sl] ^ (g4 << 4))) = bits;
+        }
+      }
+    }
+    __syncthreads();                       // mid complete
+
+    // ================= phase B: y = act(conv3x3/s2(mid) + b2), 32 pixels x 64 couts per wave =================
+    f32x16 acc2[2] = {bias2[0], bias2[1]};
+#pragma unroll
+    for (int tap = 0; tap < ((a.debug & 4) ? 0 : 9); ++tap) {
+      const int dh = tap / 3, dw = tap - 3 * dh;
+      const int my = 2 * qy + dh, mxh = qx + (dw >> 1);
+      const int R = (dw & 1) ? OD_BASE + my * OD_COLS + mxh : my * EV_COLS + mxh;
+      const char* const rowp = s_mid + R * 64;
+      const int sw = (R >> 2) & 3;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int g = ks * 2 + khalf;
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(rowp + ((g ^ sw) << 4));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(s_w2 + (i * 32 + r32) * W2_PITCH + (tap * 32 + g * 8) * 2);
+          acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc2[i], 0, 0, 0);
+        }
+      }
+    }
+    // epilogue: lane = pixel, registers = couts -> staging [16 pixels][64 couts] -> 16 B per lane, 128 B per pixel
+    char* const stg = s_out + wave * (16 * SP);
+    bf16_t* const ybase = a.y + a.out_c_offset + (lane & 7) * 8;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      if ((r32 >> 4) == hh) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16_t)act(acc2[i][g4 * 4 + e]);
+            *reinterpret_cast<bf16x4*>(stg + (r32 & 15) * SP + (i * 32 + g4 * 8 + khalf * 4) * 2) = o;
+          }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int row = pass * 8 + (lane >> 3);
+        const int q = wave * 32 + hh * 16 + row;
+        const int oy = oy0 + (q >> 4), ox = ox0 + (q & 15);
+        if (oy < a.ho && ox < a.wo && !(a.debug & 8)) {
+          const u32x4 val = *reinterpret_cast<const u32x4*>(stg + row * SP + (lane & 7) * 16);
+          *reinterpret_cast<u32x4*>(ybase + ((long)(b * a.ho + oy) * a.wo + ox) * a.out_c_total) = val;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int yolo_stem_supported(int cin_real, int c1, int c2, int h, int w) {
+  return cin_real >= 1 && cin_real <= 8 && c1 == 32 && c2 == 64 && h >= 2 && w >= 2;
+}
+
+extern "C" int yolo_stem_fwd(const float* x_nchw, int cin_real, const void* w1_packed, const float* b1, int kpad1,
+                             const void* w2_packed, const float* b2, void* y, const YoloConvDesc* dp, yolo_stream_t s) {
+  YOLO_REQUIRE(x_nchw && w1_packed && b1 && w2_packed && b2 && y && dp, "stem: null pointer");
+  const YoloConvDesc& d = *dp;     // the stride-2 conv: h x w = size of x and of the intermediate, cin 32, cout 64
+  YOLO_REQUIRE(yolo_stem_supported(cin_real, d.cin, d.cout, d.h, d.w), "stem: needs 1..8 input channels, 32 -> 64 channels");
+  YOLO_REQUIRE(d.ksize == 3 && d.stride == 2 && d.pad == 1 && d.ho == (d.h - 1) / 2 + 1 && d.wo == (d.w - 1) / 2 + 1 &&
+                   !d.upsample2x && d.out_dtype == YOLO_DT_BF16,
+               "stem: descriptor must be the 3x3 / stride 2 / pad 1 conv");
+  YOLO_REQUIRE(d.out_c_offset % 8 == 0 && d.out_c_total % 8 == 0 && d.out_c_offset + d.cout <= d.out_c_total, "stem: bad output view");
+  YOLO_REQUIRE(kpad1 >= 80 && kpad1 % 8 == 0 && d.kpad >= 288 && d.kpad % 8 == 0, "stem: bad weight packing");
+  StemArgs a;
+  a.x = x_nchw;
+  a.w1 = (const bf16_t*)w1_packed;
+  a.b1 = b1;
+  a.w2 = (const bf16_t*)w2_packed;
+  a.b2 = b2;
+  a.y = (bf16_t*)y;
+  a.n = d.n;
+  a.h = d.h;
+  a.w = d.w;
+  a.cin_real = cin_real;
+  a.ho = d.ho;
+  a.wo = d.wo;
+  a.out_c_total = d.out_c_total;
+  a.out_c_offset = d.out_c_offset;
+  a.kpad1 = kpad1;
+  a.kpad2 = d.kpad;
+  a.act = d.act;
+  static const int dbg = getenv("YOLO_STEM_DEBUG") ? atoi(getenv("YOLO_STEM_DEBUG")) : 0;
+  a.debug = dbg;
+  static const int n_cu = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    return v;
+  }();
+  const long tiles = (long)d.n * ((d.ho + 15) / 16) * ((d.wo + 15) / 16);
+  if (tiles > 0x7fffffffL) return yolo_set_error(YOLO_E_UNSUPPORTED, "stem: too many tiles");
+  const long grid = tiles < n_cu ? tiles : n_cu;       // one persistent block per CU (144 KB LDS each)
+  if (d.act == YOLO_ACT_LEAKY01)
+    hipLaunchKernelGGL(stem_kernel<true>, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)s, a);
+  else
+    hipLaunchKernelGGL(stem_kernel<false>, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)s, a);
+  return yolo_check_launch("yolo_stem_fwd");
+}

@@ -190,15 +190,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
     const int b = (int)(pix / cells), cell = (int)(pix - (long)b * cells);
     const int gy = cell / a.nx, gx = cell - gy * a.nx;
     const float r = raw[i];
-    float v;
-    if (k < 2) {
-      v = (1.f / (1.f + expf(-r)) + (float)(k == 0 ? gx : gy)) * a.stride;   // :91,:94
-    } else if (k < 4) {
-      v = (expf(r) * anchor) * a.stride;                                      // :92,:94
-    } else {
-      v = 1.f / (1.f + expf(-r));                                             // :93
-      if (a.nc == 1 && k == 5) v = 1.f;                                       // :95-96
-    }
+    const float v = yolo_decode_elem(r, k, gx, gy, anchor, a.stride, a.nc);
     const long plane_elem = (long)cell * no + k;
     if (a.p) a.p[((long)b * a.na + an) * cells * no + plane_elem] = r;
     a.io[((long)b * a.io_rows_total + a.io_row_offset + (long)an * cells) * no + plane_elem] = v;

@@ -43,6 +43,9 @@ extern "C" int yolo_run_ops(const YoloOp* ops, int n_ops, yolo_stream_t s) {
       case YOLO_OP_RESUNIT:
         rc = yolo_resunit_fwd(o.x, o.w_pre, o.bias_pre, o.w, o.bias, o.y, o.y_aux, &d, o.kpad_pre, o.cout_pad_pre, s);
         break;
+      case YOLO_OP_STEM:
+        rc = yolo_stem_fwd((const float*)o.x, d.res_c_total, o.w_pre, o.bias_pre, o.kpad_pre, o.w, o.bias, o.y, &d, s);
+        break;
       default:
         return yolo_set_error(YOLO_E_ARG, "run_ops: op %d has unknown kind %d", i, o.kind);
     }

@@ -28,7 +28,7 @@ import torch
 
 from . import kernels as K
 from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU6, DT_BF16, DT_F32, OP_CONV, OP_CONV1_NCHW, OP_DWCONV,
-                   OP_MAXPOOL, OP_RESUNIT, OP_SPP, YoloOp)
+                   OP_MAXPOOL, OP_RESUNIT, OP_SPP, OP_STEM, YoloOp)
 
 # which residual-unit widths run as ONE launch (bit mask of C: 64 | 128 | 256); see DESIGN.md §3.1d for the
 # measurements behind the default.  YOLO_FUSE_RESUNIT overrides it (tuning only).
@@ -263,7 +263,29 @@ class Plan:
               and y.c_offset % 8 == 0)
         if ok and x.buf in self._bufs:
             self._bufs.remove(x.buf)          # no packed input buffer needed
+        if ok:
+            self._try_fuse_stem(nd)
         return ok
+
+    def _try_fuse_stem(self, nd1):
+        """Darknet stem: conv1 (3x3/s1 -> 32) followed only by a 3x3/s2 32 -> 64 conv becomes ONE launch
+        (yolo_stem_fwd); the 32-channel full-resolution intermediate is never materialised."""
+        if os.environ.get("YOLO_FUSE_STEM", "1") != "1":
+            return
+        mid = nd1.outs[0]
+        if len(mid.consumers) != 1 or mid.consumers[0].kind != "conv" or mid.c_offset != 0 or mid.buf.c_total != mid.c:
+            return
+        nd2 = mid.consumers[0]
+        w2, _ = nd2.attrs["weight"]
+        y = nd2.outs[0]
+        if (tuple(w2.shape) != (64, 32, 3, 3) or nd2.attrs["stride"] != 2 or nd2.attrs["has_res"] or len(nd2.outs) != 1
+                or "up_into" in nd2.attrs or y.f32 or nd2.attrs["act"] != nd1.attrs["act"] or nd2.srcs[0] is not mid
+                or y.c_offset % 8 or "fuse_pre" in nd2.attrs):
+            return
+        nd2.attrs["stem_pre"] = nd1
+        nd1.attrs["fused_away"] = True
+        if mid.buf in self._bufs:
+            self._bufs.remove(mid.buf)
 
     def _alloc(self):
         for b in self._bufs:
@@ -284,7 +306,23 @@ class Plan:
         for nd in self.rec.nodes:
             if nd.attrs.get("fused_away"):
                 continue
-            if nd.kind == "conv" and "fuse_pre" in nd.attrs:
+            if nd.kind == "conv" and "stem_pre" in nd.attrs:
+                nd1 = nd.attrs["stem_pre"]
+                mid, y = nd.srcs[0], nd.outs[0]
+                w1p, b1p, kpad1, _ = K.pack_conv_weight(*nd1.attrs["weight"], 8)
+                w2p, b2p, kpad2, cout_pad2 = K.pack_conv_weight(*nd.attrs["weight"], 32)
+                w1p, b1p, w2p, b2p = (self._dev(t) for t in (w1p, b1p, w2p, b2p))
+                assert not ops and self.fused_input            # feed() patches op 0's x with the caller's batch
+                op = YoloOp()
+                op.kind = OP_STEM
+                op.x, op.y = None, y.buf.tensor.data_ptr()
+                op.w, op.bias, op.w_pre, op.bias_pre, op.kpad_pre = w2p.data_ptr(), b2p.data_ptr(), w1p.data_ptr(), b1p.data_ptr(), kpad1
+                op.conv = K.conv_desc(n=mid.n, h=mid.h, w=mid.w, cin=32, in_c_total=32, in_c_offset=0, cout=64,
+                                      out_c_total=y.buf.c_total, out_c_offset=y.c_offset, ksize=3, stride=2,
+                                      act=_ACT[nd.attrs["act"]], kpad=kpad2, cout_pad=cout_pad2)
+                op.conv.res_c_total = self.rec.c_in            # real input channels
+                ops.append(op)
+            elif nd.kind == "conv" and "fuse_pre" in nd.attrs:
                 pa = nd.attrs["fuse_pre"]
                 x, y, mid = nd.srcs[1], nd.outs[0], nd.srcs[0]
                 aux = nd.outs[1] if len(nd.outs) > 1 else None
@@ -427,6 +465,9 @@ class Plan:
                 cin = self.rec.c_in if first else d.cin      # the first layer's 3 -> 8 channel pad is not work
                 first = False
                 total += 2.0 * d.n * d.ho * d.wo * d.cout * d.ksize * d.ksize * cin
+            elif op.kind == OP_STEM:                         # conv1 (real input channels) + the stride-2 conv
+                first = False
+                total += 2.0 * d.n * d.h * d.w * 32 * 9 * self.rec.c_in + 2.0 * d.n * d.ho * d.wo * 64 * 9 * 32
             elif op.kind == OP_RESUNIT:                      # 1x1 C->C/2 plus 3x3 C/2->C (the halo recompute is not work)
                 total += 2.0 * d.n * d.h * d.w * (d.cout * d.cin) * 10
             elif op.kind == OP_DWCONV:

@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU6, DT_BF16, DT_F32, YoloConvDesc,
                    check, load)
 
-__all__ = ["stream_ptr", "pack_input", "conv2d", "resunit", "resunit_supported", "maxpool", "spp", "dwconv3x3", "decode",
+__all__ = ["stream_ptr", "pack_input", "conv2d", "stem", "resunit", "resunit_supported", "maxpool", "spp", "dwconv3x3", "decode",
            "nms_merge", "pack_conv_weight", "roundup", "run_ops"]
 
 
@@ -80,6 +80,14 @@ def conv2d(x, w_packed, bias, y, desc: YoloConvDesc, residual=None, y_preadd=Non
     _need_cuda(x, w_packed, bias, y, residual, y_preadd)
     check(load().yolo_conv2d_fwd(_ptr(x), _ptr(w_packed), _ptr(bias), _ptr(residual), _ptr(y), _ptr(y_preadd),
                                  C.byref(desc), stream_ptr()), "conv2d")
+    return y
+
+
+def stem(x_nchw, cin_real, w1_packed, b1, kpad1, w2_packed, b2, y, desc: YoloConvDesc):
+    """conv3x3/s1 (cin_real -> 32) + conv3x3/s2 (32 -> 64) straight from the float32 NCHW batch (yolo_stem_fwd)."""
+    _need_cuda(x_nchw, w1_packed, b1, w2_packed, b2, y)
+    check(load().yolo_stem_fwd(_ptr(x_nchw), cin_real, _ptr(w1_packed), _ptr(b1), kpad1, _ptr(w2_packed), _ptr(b2), _ptr(y),
+                               C.byref(desc), stream_ptr()), "stem")
     return y
 
 

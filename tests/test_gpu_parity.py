@@ -169,6 +169,35 @@ def test_fused_residual_unit(n, h, w, c, use_aux):
     assert float(diff.max()) <= 0.07 and float((diff > 0).float().mean()) < 0.25, (float(diff.max()), float((diff > 0).float().mean()))
 
 
+@pytest.mark.parametrize("n,cin,h,w", [(2, 3, 64, 64), (1, 3, 70, 106), (1, 1, 37, 50), (2, 3, 192, 352)])
+def test_fused_stem(n, cin, h, w):
+    """yolo_stem_fwd (conv3x3/s1 cin->32 + conv3x3/s2 32->64 from the float32 NCHW batch in one launch) against fp32
+    torch on the same bf16-rounded operands (intermediate rounded to bf16 like the two-kernel path stores it);
+    odd sizes exercise partial tiles, image borders of both convs and the zero padding of the intermediate."""
+    from pytorch_yolo_amd import kernels as K
+    from pytorch_yolo_amd._lib import ACT_LEAKY01
+    g = torch.Generator().manual_seed(h * w + cin)
+    x = torch.rand(n, cin, h, w, generator=g)
+    w1 = torch.randn(32, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b1 = torch.randn(32, generator=g) * 0.1
+    w2 = torch.randn(64, 32, 3, 3, generator=g) * (2.0 / (32 * 9)) ** 0.5
+    b2 = torch.randn(64, generator=g) * 0.1
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    w1p, b1p, kpad1, _ = K.pack_conv_weight(w1, b1, 8)
+    w2p, b2p, kpad2, cpad2 = K.pack_conv_weight(w2, b2, 32)
+    assert kpad1 >= 80
+    out_ct, out_co = 80, 8
+    y = torch.full((n, ho, wo, out_ct), -77.0, dtype=torch.bfloat16, device=DEV)
+    d = K.conv_desc(n=n, h=h, w=w, cin=32, in_c_total=32, in_c_offset=0, cout=64, out_c_total=out_ct, out_c_offset=out_co,
+                    ksize=3, stride=2, act=ACT_LEAKY01, kpad=kpad2, cout_pad=cpad2)
+    K.stem(x.to(DEV), cin, w1p.to(DEV), b1p.to(DEV), kpad1, w2p.to(DEV), b2p.to(DEV), y, d)
+    torch.cuda.synchronize()
+    mid = _bf16r(F.leaky_relu(F.conv2d(_bf16r(x), _bf16r(w1), b1, padding=1), 0.1))
+    ref = F.leaky_relu(F.conv2d(mid, _bf16r(w2), b2, stride=2, padding=1), 0.1)
+    torch.testing.assert_close(_nchw(y[..., out_co:out_co + 64]), ref, rtol=1e-2, atol=2e-2)
+    assert torch.all(y[..., :out_co] == -77.0) and torch.all(y[..., out_co + 64:] == -77.0)
+
+
 @pytest.mark.parametrize("cin,h,w", [(3, 37, 50), (3, 64, 64), (1, 20, 33), (8, 16, 16)])
 def test_first_layer_fused_with_input_packing(cin, h, w):
     """yolo_conv1_nchw_f32_fwd: the first ConvBlock reads the float32 NCHW batch directly (no packed copy)."""

@@ -13,7 +13,7 @@ import torch
 import _cases as C
 from pytorch_yolo_amd import YOLOv3SPP, YOLOv3Tiny, YOLOv3TinyMobile, _lib, engine
 from pytorch_yolo_amd import kernels as K
-from pytorch_yolo_amd._lib import OP_CONV, OP_CONV1_NCHW, OP_RESUNIT, OP_DWCONV, OP_MAXPOOL, OP_SPP
+from pytorch_yolo_amd._lib import OP_CONV, OP_CONV1_NCHW, OP_RESUNIT, OP_STEM, OP_DWCONV, OP_MAXPOOL, OP_SPP
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -106,9 +106,11 @@ def test_planner_spp_fusions():
     plan = _dry_plan(YOLOv3SPP(anchors=C.SPP_ANCHORS).eval(), 640)
     ops = _ops(plan)
     kinds = [o.kind for o in ops]
-    assert ops[0].kind == OP_CONV1_NCHW and plan.fused_input                              # first layer reads the NCHW f32 batch itself
+    # the stem (conv1 + the stride-2 conv) reads the NCHW f32 batch itself and is ONE launch (yolo_stem_fwd)
+    assert ops[0].kind == OP_STEM and plan.fused_input and kinds.count(OP_STEM) == 1
+    assert (ops[0].conv.h, ops[0].conv.ho, ops[0].conv.cout, ops[0].conv.res_c_total) == (640, 320, 64, 3)
     # no add / cat / upsample / pack launches; the 64-channel residual unit at 320^2 is ONE launch (yolo_resunit_fwd)
-    assert kinds.count(OP_CONV) == 73 and kinds.count(OP_RESUNIT) == 1 and kinds.count(OP_SPP) == 1 and len(ops) == 76
+    assert kinds.count(OP_CONV) == 72 and kinds.count(OP_RESUNIT) == 1 and kinds.count(OP_SPP) == 1 and len(ops) == 75
     unit = ops[kinds.index(OP_RESUNIT)]
     assert (unit.conv.cout, unit.conv.cin, unit.conv.h) == (64, 32, 320) and unit.y != unit.x and unit.w_pre and unit.bias_pre
     convs = [o for o in ops if o.kind == OP_CONV]
