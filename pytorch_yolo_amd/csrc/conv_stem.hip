@@ -34,7 +34,7 @@ struct StemArgs {
   int debug;            // timing ablations (YOLO_STEM_DEBUG): 1 no input loads, 2 no phase A, 4 no phase B, 8 no stores
 };
 
-template <bool LEAKY>
+template <bool LEAKY, int CIN>
 __global__ __launch_bounds__(512) void stem_kernel(const StemArgs a) {
   constexpr int NW = 8;
   constexpr int IW = 35, IP = IW * IW;                 // input halo (pixels)
@@ -115,51 +115,84 @@ __global__ __launch_bounds__(512) void stem_kernel(const StemArgs a) {
     tapoff[ks] = (dh * IW + dw) * 16;
   }
 
-  // ---- input halo pixels owned by this thread (3 of the 1225), prefetched one tile ahead into registers
+  // ---- input halo pixels owned by this thread (3 of the 1225), prefetched one tile ahead into registers.
+  // Everything per-lane is tile-invariant (offset inside the halo); a tile contributes one scalar base, and only
+  // border tiles test pixels against the image.
+  constexpr int NCH = CIN ? CIN : 8;                     // channels held in registers
   const long plane = (long)a.h * a.w;
-  float pre[3][8];
-  auto fetch = [&](int t) {
-    const int tx = t % tiles_x, r = t / tiles_x;
-    const int ty = r % tiles_y, b = r / tiles_y;
+  int h_rel[3], h_yx[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int hp = tid + u * 512;
+    const int hy = hp / IW, hx = hp - hy * IW;
+    h_rel[u] = hp < IP ? hy * a.w + hx : -1;
+    h_yx[u] = (hy << 8) | hx;
+  }
+  float pre[3][NCH];
+  auto fetch = [&](int b, int ty, int tx) {
     const int iy0 = 2 * ty * 16 - 2, ix0 = 2 * tx * 16 - 2;     // halo origin in input coordinates
+    const float* const base = a.x + ((long)b * a.cin_real) * plane + (long)iy0 * a.w + ix0;
+    const bool interior = iy0 >= 0 && iy0 + IW <= a.h && ix0 >= 0 && ix0 + IW <= a.w && !(a.debug & 1);
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
-      const int hp = tid + u * 512;
-      const int hy = hp / IW, hx = hp - hy * IW;
-      const int yy = iy0 + hy, xx = ix0 + hx;
-      const bool ok = hp < IP && (unsigned)yy < (unsigned)a.h && (unsigned)xx < (unsigned)a.w && !(a.debug & 1);
-      const float* src = a.x + ((long)b * a.cin_real) * plane + (long)yy * a.w + xx;
+      bool ok = h_rel[u] >= 0;
+      if (!interior)
+        ok = ok && (unsigned)(iy0 + (h_yx[u] >> 8)) < (unsigned)a.h && (unsigned)(ix0 + (h_yx[u] & 255)) < (unsigned)a.w &&
+             !(a.debug & 1);
+      const float* src = base + h_rel[u];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) pre[u][e] = (ok && e < a.cin_real) ? src[e * plane] : 0.f;
+      for (int e = 0; e < NCH; ++e) pre[u][e] = (ok && (CIN || e < a.cin_real)) ? src[e * plane] : 0.f;
     }
   };
   auto commit = [&]() {
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
-      const int hp = tid + u * 512;
-      if (hp >= IP) continue;
+      if (h_rel[u] < 0) continue;
       bf16x8 v;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (bf16_t)pre[u][e];
-      *reinterpret_cast<bf16x8*>(s_in + hp * 16) = v;
+      for (int e = 0; e < 8; ++e) v[e] = e < NCH ? (bf16_t)pre[u][e] : (bf16_t)0.f;
+      *reinterpret_cast<bf16x8*>(s_in + (tid + u * 512) * 16) = v;
     }
   };
+
+  // output rows of this lane in the store passes (tile-invariant part of the address)
+  int o_rel[4], o_yx[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int q = wave * 32 + k * 8 + (lane >> 3);          // k = hh*2 + pass
+    o_rel[k] = ((q >> 4) * a.wo + (q & 15)) * a.out_c_total + a.out_c_offset + (lane & 7) * 8;
+    o_yx[k] = ((q >> 4) << 8) | (q & 15);
+  }
 
   // phase B fragment rows: output pixel q = wave*32 + r32 of the 16 x 16 tile
   const int qy = (wave * 32 + r32) >> 4, qx = r32 & 15;
 
-  fetch(t_lo);
+  // tile cursor (image, tile row, tile col) advanced without divisions; `n*` = the tile being prefetched
+  int tx = t_lo % tiles_x, ty = (t_lo / tiles_x) % tiles_y, b = t_lo / (tiles_x * tiles_y);
+  int ntx = tx, nty = ty, nb = b;
+  auto advance = [&](int& x_, int& y_, int& b_) {
+    if (++x_ == tiles_x) {
+      x_ = 0;
+      if (++y_ == tiles_y) {
+        y_ = 0;
+        ++b_;
+      }
+    }
+  };
+  fetch(b, ty, tx);
 #pragma unroll
   for (int j = 0; j < 5; ++j) {                        // issued before fetch(): landed by the time fetch's data is
     const int i = tid + j * 512, row = i / 36, piece = i - row * 36;
     if (i < 64 * 36) *reinterpret_cast<u32x4*>(s_w2 + row * W2_PITCH + piece * 16) = w2tmp[j];
   }
-  for (int t = t_lo; t < t_hi; ++t) {
-    const int tx = t % tiles_x, tr = t / tiles_x;
-    const int ox0 = tx * 16, oy0 = (tr % tiles_y) * 16, b = tr / tiles_y;
+  for (int t = t_lo; t < t_hi; ++t, advance(tx, ty, b)) {
+    const int ox0 = tx * 16, oy0 = ty * 16;
     commit();
     __syncthreads();                       // input halo t (and, first time, W2) in LDS; every wave has left phase B of t-1
-    if (t + 1 < t_hi) fetch(t + 1);        // global loads fly during both MFMA phases
+    if (t + 1 < t_hi) {                    // global loads fly during both MFMA phases
+      advance(ntx, nty, nb);
+      fetch(nb, nty, ntx);
+    }
 
     // ================= phase A: mid = act(conv3x3/s1(x) + b1) on the 33 x 33 halo -> LDS =================
     // tiles whose whole 33 x 33 halo lies inside the image (all but the border tiles) need no per-pixel test
@@ -214,7 +247,8 @@ __global__ __launch_bounds__(512) void stem_kernel(const StemArgs a) {
     }
     // epilogue: lane = pixel, registers = couts -> staging [16 pixels][64 couts] -> 16 B per lane, 128 B per pixel
     char* const stg = s_out + wave * (16 * SP);
-    bf16_t* const ybase = a.y + a.out_c_offset + (lane & 7) * 8;
+    bf16_t* const ytile = a.y + ((long)(b * a.ho + oy0) * a.wo + ox0) * a.out_c_total;
+    const bool full = oy0 + 16 <= a.ho && ox0 + 16 <= a.wo;
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
       if ((r32 >> 4) == hh) {
@@ -231,12 +265,11 @@ __global__ __launch_bounds__(512) void stem_kernel(const StemArgs a) {
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {
-        const int row = pass * 8 + (lane >> 3);
-        const int q = wave * 32 + hh * 16 + row;
-        const int oy = oy0 + (q >> 4), ox = ox0 + (q & 15);
-        if (oy < a.ho && ox < a.wo && !(a.debug & 8)) {
-          const u32x4 val = *reinterpret_cast<const u32x4*>(stg + row * SP + (lane & 7) * 16);
-          *reinterpret_cast<u32x4*>(ybase + ((long)(b * a.ho + oy) * a.wo + ox) * a.out_c_total) = val;
+        const int k = hh * 2 + pass;
+        const bool ok = (full || (oy0 + (o_yx[k] >> 8) < a.ho && ox0 + (o_yx[k] & 255) < a.wo)) && !(a.debug & 8);
+        if (ok) {
+          const u32x4 val = *reinterpret_cast<const u32x4*>(stg + (pass * 8 + (lane >> 3)) * SP + (lane & 7) * 16);
+          *reinterpret_cast<u32x4*>(ytile + o_rel[k]) = val;
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -289,9 +322,15 @@ extern "C" int yolo_stem_fwd(const float* x_nchw, int cin_real, const void* w1_p
   const long tiles = (long)d.n * ((d.ho + 15) / 16) * ((d.wo + 15) / 16);
   if (tiles > 0x7fffffffL) return yolo_set_error(YOLO_E_UNSUPPORTED, "stem: too many tiles");
   const long grid = tiles < n_cu ? tiles : n_cu;       // one persistent block per CU (144 KB LDS each)
-  if (d.act == YOLO_ACT_LEAKY01)
-    hipLaunchKernelGGL(stem_kernel<true>, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)s, a);
-  else
-    hipLaunchKernelGGL(stem_kernel<false>, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)s, a);
+  const dim3 g((unsigned)grid), blk(512);
+  hipStream_t st = (hipStream_t)s;
+  const bool leaky = d.act == YOLO_ACT_LEAKY01;
+  if (cin_real == 3) {
+    if (leaky) hipLaunchKernelGGL((stem_kernel<true, 3>), g, blk, 0, st, a);
+    else hipLaunchKernelGGL((stem_kernel<false, 3>), g, blk, 0, st, a);
+  } else {
+    if (leaky) hipLaunchKernelGGL((stem_kernel<true, 0>), g, blk, 0, st, a);
+    else hipLaunchKernelGGL((stem_kernel<false, 0>), g, blk, 0, st, a);
+  }
   return yolo_check_launch("yolo_stem_fwd");
 }
