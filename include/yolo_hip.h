@@ -132,6 +132,16 @@ YOLO_API int yolo_decode_fwd(const float* head, int head_c_total, const float* a
                     int ny, int nx, float stride_px, float* io, int io_rows_total, int io_row_offset,
                     float* p, yolo_stream_t s);
 
+/* ---- detection head in one launch: head conv (1x1 or 3x3, stride 1; bias; act none for the plain heads of
+ *  yolov3_tiny.py:38,42, leaky for the ConvBlock heads of yolov3_spp.py:104) with YOLOLayer.forward's eval branch
+ *  as its epilogue: p[bs,na,ny,nx,5+nc] = the raw head values, io rows = the decoded ones (see yolo_decode_fwd).
+ *  The NHWC head tensor is never materialised.  d = the head conv (cout = na*(5+nc) <= 256; its output view is
+ *  ignored).  yolo_head_decode_supported(): na <= 4, 5+nc <= 128; other heads use yolo_conv2d_fwd + yolo_decode_fwd. */
+YOLO_API int yolo_head_decode_supported(int cout, int na, int nc);
+YOLO_API int yolo_head_decode_fwd(const void* x, const void* w_packed, const float* bias, const YoloConvDesc* d,
+                                  const float* anchors_px, int na, int nc, float stride_px, float* io,
+                                  int io_rows_total, int io_row_offset, float* p, yolo_stream_t s);
+
 /* ---- non_max_suppression, 'MERGE' style (utils/utils.py:200-293; xywh2xyxy :46-60, bbox_iou :63-96).
  *  pred: f32 [bs,rows,5+nc].  If mutate_conf != 0 column 4 is overwritten with obj*max_cls like the
  *  reference (:213); otherwise pred is read-only.
@@ -152,7 +162,7 @@ YOLO_API int yolo_scale_coords(float* dets, int bs, int cap, int row_floats, con
 
 /* ---- batched launcher: run a recorded list of ops with one FFI crossing (host overhead only). */
 enum { YOLO_OP_CONV = 1, YOLO_OP_MAXPOOL = 2, YOLO_OP_SPP = 3, YOLO_OP_DWCONV = 4, YOLO_OP_CONV1_NCHW = 5,
-       YOLO_OP_RESUNIT = 6, YOLO_OP_STEM = 7 };
+       YOLO_OP_RESUNIT = 6, YOLO_OP_STEM = 7, YOLO_OP_HEAD_DECODE = 8 };
 typedef struct YoloOp {
   int32_t kind, _pad;
   const void* x; const void* w; const float* bias; const void* residual; void* y; void* y_aux;
@@ -164,6 +174,9 @@ typedef struct YoloOp {
                                     res_c_total = real input channels, see yolo_stem_fwd */
   const void* w_pre; const float* bias_pre;   /* RESUNIT / STEM: packed W1 / b1 of the leading conv */
   int32_t kpad_pre, cout_pad_pre;
+  /* HEAD_DECODE (yolo_head_decode_fwd): y = io, y_aux = p (nullable), conv = the head conv */
+  float head_anchors_px[8]; float head_stride_px;
+  int32_t head_na, head_nc, io_rows_total, io_row_offset, _pad2;
 } YoloOp;
 YOLO_API int yolo_run_ops(const YoloOp* ops, int n_ops, yolo_stream_t s);
 

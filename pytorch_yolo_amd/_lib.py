@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libyolo_hip.so")
 
 ACT_NONE, ACT_LEAKY01, ACT_RELU6 = 0, 1, 2
 DT_BF16, DT_F32 = 0, 1
-OP_CONV, OP_MAXPOOL, OP_SPP, OP_DWCONV, OP_CONV1_NCHW, OP_RESUNIT, OP_STEM = 1, 2, 3, 4, 5, 6, 7
+OP_CONV, OP_MAXPOOL, OP_SPP, OP_DWCONV, OP_CONV1_NCHW, OP_RESUNIT, OP_STEM, OP_HEAD_DECODE = 1, 2, 3, 4, 5, 6, 7, 8
 
 
 class YoloConvDesc(C.Structure):
@@ -29,7 +29,10 @@ class YoloOp(C.Structure):
                 ("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p),
                 ("residual", C.c_void_p), ("y", C.c_void_p), ("y_aux", C.c_void_p),
                 ("conv", YoloConvDesc),
-                ("w_pre", C.c_void_p), ("bias_pre", C.c_void_p), ("kpad_pre", C.c_int32), ("cout_pad_pre", C.c_int32)]
+                ("w_pre", C.c_void_p), ("bias_pre", C.c_void_p), ("kpad_pre", C.c_int32), ("cout_pad_pre", C.c_int32),
+                ("head_anchors_px", C.c_float * 8), ("head_stride_px", C.c_float),
+                ("head_na", C.c_int32), ("head_nc", C.c_int32), ("io_rows_total", C.c_int32),
+                ("io_row_offset", C.c_int32), ("_pad2", C.c_int32)]
 
 
 # symbol -> (restype, argtypes); kept in one table so tests can check it against the header
@@ -51,6 +54,9 @@ SIGNATURES = {
     "yolo_spp_fwd": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
     "yolo_decode_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 5 + [C.c_float, C.c_void_p,
                                   C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "yolo_head_decode_supported": (C.c_int, [C.c_int] * 3),
+    "yolo_head_decode_fwd": (C.c_int, [C.c_void_p] * 3 + [C.POINTER(YoloConvDesc), C.c_void_p, C.c_int, C.c_int, C.c_float,
+                                       C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "yolo_nms_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
     "yolo_nms_merge": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [C.c_float] * 3 + [C.c_int] * 2 +
                        [C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),

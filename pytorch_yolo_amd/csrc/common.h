@@ -37,10 +37,15 @@ __device__ __forceinline__ float bf16_bits_to_f32(uint32_t hi16) { return __uint
 // (0,1 = x,y; 2,3 = w,h; 4 = objectness; 5.. = classes) at grid cell (gx, gy); anchor = anchor_px / stride for
 // this role.  Shared by the standalone decode kernel and the head-conv epilogue so that both give the same bits.
 __device__ __forceinline__ float yolo_decode_elem(float r, int k, int gx, int gy, float anchor, float stride, int nc) {
-  if (k < 2) return (1.f / (1.f + expf(-r)) + (float)(k == 0 ? gx : gy)) * stride;   // :91,:94
-  if (k < 4) return (expf(r) * anchor) * stride;                                      // :92,:94
-  if (nc == 1 && k == 5) return 1.f;                                                  // :95-96
-  return 1.f / (1.f + expf(-r));                                                      // :93
+  // one exponential and one division per element whatever the role (the roles differ per lane inside a wave)
+  const bool wh = (k & ~1) == 2;
+  const float e = expf(wh ? r : -r);
+  const float sg = 1.f / (1.f + e);                                   // sigmoid(r) where it is used
+  float v = sg;                                                       // :93
+  if (k < 2) v = (sg + (float)(k == 0 ? gx : gy)) * stride;           // :91,:94
+  if (wh) v = (e * anchor) * stride;                                  // :92,:94
+  if (nc == 1 && k == 5) v = 1.f;                                     // :95-96
+  return v;
 }
 
 // per-op launch entry points shared with the batched launcher

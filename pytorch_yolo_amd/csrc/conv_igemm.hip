@@ -32,7 +32,7 @@ namespace {
 // the instruction's scalar offset: ~3 VALU per LDS-DMA instead of ~15.
 // LDS_EPI (bf16 output, cout % 32 == 0): the finished tile goes registers -> LDS (fp32) -> global so that
 // residual read, pre-add copy and store are 16-byte-per-lane accesses over whole channel runs.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int NS, bool FAST, bool LDS_EPI, bool MFMA16 = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int NS, bool FAST, bool LDS_EPI, bool MFMA16 = false, bool DECODE = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel(const ConvArgs a) {
   constexpr int NW = WAVES_M * WAVES_N;
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
@@ -51,7 +51,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel
   static_assert(NS * STAGE_B <= 160 * 1024, "LDS");
 
   constexpr int RING_B = NS * STAGE_B;
-  constexpr int LDS_B = (LDS_EPI && NW * TM * kEpiPitch > RING_B) ? NW * TM * kEpiPitch : RING_B;   // epilogue slab reuses the ring
+  constexpr int DP = BN + 4;                           // DECODE: fp32 staging pitch (floats) of the [BM][BN] tile
+  constexpr int EPI_B = DECODE ? BM * DP * 4 : (LDS_EPI ? NW * TM * kEpiPitch : 0);
+  constexpr int LDS_B = EPI_B > RING_B ? EPI_B : RING_B;   // the epilogue staging reuses the ring
+  static_assert(!DECODE || (!LDS_EPI && !MFMA16 && BM % NW == 0), "DECODE instances use the plain 32x32 accumulators");
   __shared__ __attribute__((aligned(16))) char smem[LDS_B];   // per stage: [BNL weight rows][BM pixel rows]
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -311,7 +314,73 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel
   }
   // ---- epilogue: lane = pixel (col), registers = couts (row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) ----
   const bool f32_out = d.out_dtype == YOLO_DT_F32;
-  if constexpr (LDS_EPI && MFMA16) {
+  if constexpr (DECODE) {
+    // Head conv + YOLOLayer decode (yolo_layer.py:57-69,90-96): the tile [BM pixels][na*(5+nc) couts] is staged in
+    // LDS as fp32, then each wave walks its pixels; per (pixel, anchor) the lanes take k = lane, lane + 64 of the
+    // (5+nc)-run, so the raw logits go to p and the decoded values to io as contiguous 340-byte runs that the
+    // next pixel continues.  The head tensor itself is never written.
+    __syncthreads();                                 // every wave is done with the last stage: LDS is free
+    float* const stg = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int c0 = wn * TN + i * 32 + g4 * 8 + khalf * 4;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (c0 < d.cout_pad) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + c0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[i][j][g4 * 4 + e] + bv[e], d.act);
+          }
+          *reinterpret_cast<f32x4*>(stg + (wm * TM + j * 32 + r32) * DP + c0) = v;
+        }
+    __syncthreads();
+    const HeadDecodeArgs& h = a.hd;
+    constexpr int PPW = BM / NW;                      // pixels per wave
+    constexpr int CJ = BN / 64;                       // head channel c = lane + 64 j  ->  (anchor, role k): per-lane constants
+    int c_k[CJ];
+    long c_poff[CJ], c_ioff[CJ];                      // element offsets of (anchor, k) inside one image's p / io block
+    float c_anchor[CJ];
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) {
+      const int c = lane + 64 * j;
+      const int an = c / h.no, k = c - an * h.no;
+      const bool live = c < h.na * h.no;
+      c_k[j] = live ? k : -1;
+      c_poff[j] = (long)an * hw_out * h.no + k;
+      c_ioff[j] = ((long)h.io_row_offset + (long)an * hw_out) * h.no + k;
+      c_anchor[j] = live ? (k == 2 ? h.anchor_w[an] : h.anchor_h[an]) : 0.f;
+    }
+    int m = m0 + wave * PPW;
+    if (m < a.M) {
+      int b = m / hw_out, cell = m - b * hw_out;
+      int gy = cell / d.wo, gx = cell - gy * d.wo;
+      for (int i = 0; i < PPW && m < a.M; ++i, ++m) {
+        const float* const srow = stg + (wave * PPW + i) * DP;
+        float* const pimg = h.p ? h.p + ((long)b * h.na * hw_out + cell) * h.no : nullptr;
+        float* const iimg = h.io + ((long)b * h.io_rows_total + cell) * h.no;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+          if (c_k[j] < 0) continue;
+          const float r = srow[lane + 64 * j];
+          const float v = yolo_decode_elem(r, c_k[j], gx, gy, c_anchor[j], h.stride, h.no - 5);
+          if (pimg) pimg[c_poff[j]] = r;
+          iimg[c_ioff[j]] = v;
+        }
+        ++cell;
+        if (++gx == d.wo) {
+          gx = 0;
+          if (++gy == d.ho) {
+            gy = 0;
+            cell = 0;
+            ++b;
+          }
+        }
+      }
+    }
+  } else if constexpr (LDS_EPI && MFMA16) {
     __syncthreads();
     epilogue_lds16<MI, NI16, TM>(a, acc16, smem + wave * (TM * kEpiPitch), lane, n0 + wn * TN, pix_of);
   } else if constexpr (LDS_EPI) {
@@ -388,7 +457,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int NS, bool FAST, bool LDS_EPI, bool MFMA16 = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int NS, bool FAST, bool LDS_EPI, bool MFMA16 = false, bool DECODE = false>
 int launch_cfg(const ConvArgs& a, hipStream_t s) {
   const int m_tiles = (a.M + BM - 1) / BM;
   ConvArgs b = a;
@@ -396,7 +465,7 @@ int launch_cfg(const ConvArgs& a, hipStream_t s) {
   b.steps = (a.d.ksize * a.d.ksize * a.d.cin + BK - 1) / BK;   // kpad >= steps*BK: the K tail is zero-padded
   const long grid = (long)m_tiles * b.n_tiles;
   if (grid > 0x7fffffffL) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv grid too large");
-  hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, BK, NS, FAST, LDS_EPI, MFMA16>), dim3((unsigned)grid),
+  hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, BK, NS, FAST, LDS_EPI, MFMA16, DECODE>), dim3((unsigned)grid),
                      dim3(64 * WAVES_M * WAVES_N), 0, s, b);
   return yolo_check_launch("yolo_conv2d_fwd");
 }
@@ -406,9 +475,17 @@ int conv_debug_flags = 0;   // tuning hook (YOLO_CONV_VARIANT), see yolo_conv2d_
 
 }  // namespace
 
+static int conv2d_launch_ex(const void* x, const void* w, const float* bias, const void* res, void* y, void* y_aux,
+                            const YoloConvDesc* dp, const HeadDecodeArgs* hd, hipStream_t s);
+
 int yolo_conv2d_launch(const void* x, const void* w, const float* bias, const void* res, void* y, void* y_aux,
                        const YoloConvDesc* dp, hipStream_t s) {
-  YOLO_REQUIRE(x && w && bias && y && dp, "conv: null pointer");
+  return conv2d_launch_ex(x, w, bias, res, y, y_aux, dp, nullptr, s);
+}
+
+static int conv2d_launch_ex(const void* x, const void* w, const float* bias, const void* res, void* y, void* y_aux,
+                            const YoloConvDesc* dp, const HeadDecodeArgs* hd, hipStream_t s) {
+  YOLO_REQUIRE(x && w && bias && (y || hd) && dp, "conv: null pointer");
   static const bool env_read = [] {
     if (const char* e = getenv("YOLO_CONV_VARIANT")) conv_variant_override = atoi(e);
     if (const char* e = getenv("YOLO_CONV_DEBUG")) conv_debug_flags = atoi(e);
@@ -450,6 +527,11 @@ int yolo_conv2d_launch(const void* x, const void* w, const float* bias, const vo
   a.x_bytes = (uint32_t)x_bytes;
   a.w_bytes = (uint32_t)w_bytes;
   a.debug = conv_debug_flags;
+  if (hd) {   // head conv with the YOLOLayer decode as its epilogue: one 64-pixel x 256-cout tile per block
+    a.hd = *hd;
+    return d.cin % 32 == 0 ? launch_cfg<64, 256, 1, 4, 32, 2, true, false, false, true>(a, s)
+                           : launch_cfg<64, 256, 1, 4, 32, 2, false, false, false, true>(a, s);
+  }
   const int variant = conv_variant_override >= 0 ? conv_variant_override : 0;
   const bool fast64 = d.cin % 64 == 0, fast32 = d.cin % 32 == 0;
   const bool epi = d.out_dtype == YOLO_DT_BF16 && d.cout % 32 == 0 && d.out_c_offset % 8 == 0 && d.out_c_total % 8 == 0 &&
@@ -530,6 +612,40 @@ extern "C" int yolo_conv1_nchw_f32_fwd(const float* x_nchw, int cin_real, const 
 extern "C" int yolo_conv2d_fwd(const void* x, const void* w_packed, const float* bias, const void* residual, void* y,
                                void* y_preadd, const YoloConvDesc* d, yolo_stream_t s) {
   return yolo_conv2d_launch(x, w_packed, bias, residual, y, y_preadd, d, (hipStream_t)s);
+}
+
+// Head conv + decode in one launch (see the DECODE epilogue of conv_igemm_bf16_kernel).
+extern "C" int yolo_head_decode_supported(int cout, int na, int nc) {
+  return na >= 1 && na <= 4 && nc >= 1 && cout == na * (5 + nc) && cout <= 256 && 5 + nc <= 128;
+}
+
+extern "C" int yolo_head_decode_fwd(const void* x, const void* w_packed, const float* bias, const YoloConvDesc* dp,
+                                    const float* anchors_px, int na, int nc, float stride_px, float* io, int io_rows_total,
+                                    int io_row_offset, float* p, yolo_stream_t s) {
+  YOLO_REQUIRE(dp && anchors_px && io, "head_decode: null pointer");
+  const YoloConvDesc& d = *dp;
+  YOLO_REQUIRE(yolo_head_decode_supported(d.cout, na, nc), "head_decode: cout %d != na*(5+nc) = %d*%d or out of range", d.cout, na,
+               5 + nc);
+  YOLO_REQUIRE(d.stride == 1 && !d.upsample2x, "head_decode: stride-1 head convs only");
+  YOLO_REQUIRE(io_row_offset >= 0 && io_row_offset + na * d.ho * d.wo <= io_rows_total, "head_decode: rows out of range");
+  YOLO_REQUIRE(stride_px > 0.f, "head_decode: bad stride");
+  HeadDecodeArgs h;
+  h.io = io;
+  h.p = p;
+  h.na = na;
+  h.no = nc + 5;
+  h.io_rows_total = io_rows_total;
+  h.io_row_offset = io_row_offset;
+  h.stride = stride_px;
+  for (int i = 0; i < 4; ++i) {
+    h.anchor_w[i] = i < na ? anchors_px[2 * i] / stride_px : 0.f;
+    h.anchor_h[i] = i < na ? anchors_px[2 * i + 1] / stride_px : 0.f;
+  }
+  YoloConvDesc dd = d;              // the output view is unused: give the shared checks a consistent one
+  dd.out_dtype = YOLO_DT_F32;
+  dd.out_c_total = (d.cout + 3) & ~3;
+  dd.out_c_offset = 0;
+  return conv2d_launch_ex(x, w_packed, bias, nullptr, nullptr, nullptr, &dd, &h, (hipStream_t)s);
 }
 
 // Host-side weight packer: OIHW f32 -> [cout_pad][kpad] bf16, k = (kh*ks+kw)*cin + c, zero padded.

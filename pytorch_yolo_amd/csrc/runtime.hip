@@ -46,6 +46,10 @@ extern "C" int yolo_run_ops(const YoloOp* ops, int n_ops, yolo_stream_t s) {
       case YOLO_OP_STEM:
         rc = yolo_stem_fwd((const float*)o.x, d.res_c_total, o.w_pre, o.bias_pre, o.kpad_pre, o.w, o.bias, o.y, &d, s);
         break;
+      case YOLO_OP_HEAD_DECODE:
+        rc = yolo_head_decode_fwd(o.x, o.w, o.bias, &d, o.head_anchors_px, o.head_na, o.head_nc, o.head_stride_px, (float*)o.y,
+                                  o.io_rows_total, o.io_row_offset, (float*)o.y_aux, s);
+        break;
       default:
         return yolo_set_error(YOLO_E_ARG, "run_ops: op %d has unknown kind %d", i, o.kind);
     }

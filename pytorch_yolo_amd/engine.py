@@ -28,7 +28,7 @@ import torch
 
 from . import kernels as K
 from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU6, DT_BF16, DT_F32, OP_CONV, OP_CONV1_NCHW, OP_DWCONV,
-                   OP_MAXPOOL, OP_RESUNIT, OP_SPP, OP_STEM, YoloOp)
+                   OP_HEAD_DECODE, OP_MAXPOOL, OP_RESUNIT, OP_SPP, OP_STEM, YoloOp)
 
 # which residual-unit widths run as ONE launch (bit mask of C: 64 | 128 | 256); see DESIGN.md §3.1d for the
 # measurements behind the default.  YOLO_FUSE_RESUNIT overrides it (tuning only).
@@ -235,9 +235,18 @@ class Plan:
                     y.buf, y.c_offset = res.buf, res.c_offset
                 elif dead and y.buf is None and res.buf is None:
                     nd.attrs["alias_res"] = True
+        # 3b. detection heads: the head conv decodes in its epilogue (yolo_head_decode_fwd); no head tensor
+        if os.environ.get("YOLO_FUSE_HEAD", "1") == "1":
+            for nd in nodes:
+                layer = self._head_layer(nd)
+                if layer is None or nd.attrs["has_res"] or len(nd.outs) != 1 or "up_into" in nd.attrs or nd.attrs["stride"] != 1:
+                    continue
+                w, _ = nd.attrs["weight"]
+                if K.head_decode_supported(w.shape[0], len(layer.anchors_px), self.n_class) and nd.outs[0].buf is None:
+                    nd.attrs["head_fused"] = True
         # 4. everything else gets its own buffer
         for nd in nodes:
-            if nd.attrs.get("fused_away"):
+            if nd.attrs.get("fused_away") or nd.attrs.get("head_fused"):
                 continue
             for o in nd.outs:
                 if o.buf is None and not (nd.kind == "conv" and "up_into" in nd.attrs and o.slot == 0):
@@ -248,6 +257,18 @@ class Plan:
             if nd.kind == "conv" and nd.attrs.get("alias_res"):
                 res, y = nd.srcs[1], nd.outs[0]
                 y.buf, y.c_offset = res.buf, res.c_offset
+
+    def _head_layer(self, nd):
+        """The YOLOLayer fed by conv node ``nd`` (its f32 output goes to a head and nowhere else), or None."""
+        if nd.kind != "conv" or not nd.outs[0].f32:
+            return None
+        y = nd.outs[0]
+        if len(y.consumers) != 1 or y.consumers[0].kind != "head":
+            return None
+        for x, layer in self.rec.heads:
+            if x is y:
+                return layer
+        return None
 
     def _first_conv_reads_nchw(self) -> bool:
         """The first layer can read the caller's float32 NCHW batch itself (yolo_conv1_nchw_f32_fwd): then the
@@ -302,6 +323,15 @@ class Plan:
         return t
 
     def _build_ops(self):
+        # heads: io row ranges in the order the model declares them (yolov3_spp.py:156-164)
+        self.heads = []
+        row = 0
+        for x, layer in self.rec.heads:
+            na = len(layer.anchors_px)
+            stride = self.img_size / max(x.w, x.h)          # yolo_layer.py:102 (python float)
+            self.heads.append(dict(sym=x, anchors=layer.anchors_px, stride=stride, row=row, na=na, layer=layer, op=None))
+            row += na * x.h * x.w
+        self.rows_total = row
         ops = []
         for nd in self.rec.nodes:
             if nd.attrs.get("fused_away"):
@@ -321,6 +351,26 @@ class Plan:
                                       out_c_total=y.buf.c_total, out_c_offset=y.c_offset, ksize=3, stride=2,
                                       act=_ACT[nd.attrs["act"]], kpad=kpad2, cout_pad=cout_pad2)
                 op.conv.res_c_total = self.rec.c_in            # real input channels
+                ops.append(op)
+            elif nd.kind == "conv" and nd.attrs.get("head_fused"):
+                x, y = nd.srcs[0], nd.outs[0]
+                hd = next(h for h in self.heads if h["sym"] is y)
+                w, b = nd.attrs["weight"]
+                wp, bp, kpad, cout_pad = K.pack_conv_weight(w, b, x.c)
+                wp, bp = self._dev(wp), self._dev(bp)
+                op = YoloOp()
+                op.kind = OP_HEAD_DECODE
+                op.x, op.w, op.bias = x.buf.tensor.data_ptr(), wp.data_ptr(), bp.data_ptr()
+                op.y = op.y_aux = None                      # io / p of the call: bound in _bind_outputs
+                op.conv = K.conv_desc(n=x.n, h=x.h, w=x.w, cin=x.c, in_c_total=x.buf.c_total, in_c_offset=x.c_offset,
+                                      cout=w.shape[0], out_c_total=K.roundup(w.shape[0], 8), out_c_offset=0,
+                                      ksize=w.shape[2], stride=1, act=_ACT[nd.attrs["act"]], kpad=kpad,
+                                      cout_pad=cout_pad, out_dtype=DT_F32)
+                for i, (aw, ah) in enumerate(hd["anchors"]):
+                    op.head_anchors_px[2 * i], op.head_anchors_px[2 * i + 1] = float(aw), float(ah)
+                op.head_stride_px, op.head_na, op.head_nc = float(hd["stride"]), hd["na"], self.n_class
+                op.io_rows_total, op.io_row_offset = self.rows_total, hd["row"]
+                hd["op"] = len(ops)
                 ops.append(op)
             elif nd.kind == "conv" and "fuse_pre" in nd.attrs:
                 pa = nd.attrs["fuse_pre"]
@@ -403,16 +453,6 @@ class Plan:
                 ops.append(op)
         self.n_ops = len(ops)
         self.op_array = (YoloOp * len(ops))(*ops)
-        # heads
-        self.heads = []
-        row = 0
-        for x, layer in self.rec.heads:
-            na = len(layer.anchors_px)
-            stride = self.img_size / max(x.w, x.h)          # yolo_layer.py:102 (python float)
-            self.heads.append(dict(sym=x, anchors=layer.anchors_px, stride=stride, row=row, na=na, layer=layer))
-            row += na * x.h * x.w
-        self.rows_total = row
-
     # -- execution -----------------------------------------------------------------------------------
     @property
     def input_buffer(self) -> torch.Tensor:
@@ -432,14 +472,27 @@ class Plan:
         """pack -> layer list -> decodes on the current stream.  ``timing`` = (start, end) torch events
         recorded around the layer list (bench.py's roofline measurement)."""
         self.feed(x)
+        self._bind_outputs(io, ps)
         if timing is not None:
             timing[0].record()
         K.run_ops(self.op_array, self.n_ops)
         if timing is not None:
             timing[1].record()
+        self._decode_unfused(io, ps)
+
+    def _bind_outputs(self, io, ps):
+        """Heads that decode in their conv epilogue write io / p themselves: patch this call's buffers into their ops."""
+        if io.shape[1] != self.rows_total or not io.is_contiguous():
+            raise RuntimeError("io must be a contiguous [bs, rows_total, 5+nc] tensor")
         for hd, p in zip(self.heads, ps):
-            s = hd["sym"]
-            K.decode(s.buf.tensor, hd["anchors"], self.n_class, hd["stride"], io, hd["row"], p)
+            if hd["op"] is not None:
+                op = self.op_array[hd["op"]]
+                op.y, op.y_aux = io.data_ptr(), (p.data_ptr() if p is not None else None)
+
+    def _decode_unfused(self, io, ps):
+        for hd, p in zip(self.heads, ps):
+            if hd["op"] is None:
+                K.decode(hd["sym"].buf.tensor, hd["anchors"], self.n_class, hd["stride"], io, hd["row"], p)
 
     def launch_detect(self, x, io, ps, nms_out, conf_thres, nms_thres, timing=None, join=True, after_nms=None):
         """forward + decode + MERGE-NMS into caller-provided buffers; no host sync.
@@ -461,7 +514,7 @@ class Plan:
         for i in range(self.n_ops):
             op = self.op_array[i]
             d = op.conv
-            if op.kind in (OP_CONV, OP_CONV1_NCHW):
+            if op.kind in (OP_CONV, OP_CONV1_NCHW, OP_HEAD_DECODE):
                 cin = self.rec.c_in if first else d.cin      # the first layer's 3 -> 8 channel pad is not work
                 first = False
                 total += 2.0 * d.n * d.ho * d.wo * d.cout * d.ksize * d.ksize * cin
@@ -548,11 +601,12 @@ class StreamedPlan:
             lo, hi = i * self.sub, (i + 1) * self.sub
             st.wait_stream(cur)
             with torch.cuda.stream(st):
+                sub_ps = tuple(p[lo:hi] for p in ps)
                 pl.feed(x[lo:hi])
+                pl._bind_outputs(io[lo:hi], sub_ps)
                 K.run_ops(pl.op_array, pl.n_ops)
                 self._marks[i].record(st)
-                for hd, p in zip(pl.heads, ps):
-                    K.decode(hd["sym"].buf.tensor, hd["anchors"], self.n_class, hd["stride"], io[lo:hi], hd["row"], p[lo:hi])
+                pl._decode_unfused(io[lo:hi], sub_ps)
         if timing is not None:
             for m in self._marks:
                 cur.wait_event(m)

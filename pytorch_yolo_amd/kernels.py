@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU6, DT_BF16, DT_F32, YoloConvDesc,
                    check, load)
 
-__all__ = ["stream_ptr", "pack_input", "conv2d", "stem", "resunit", "resunit_supported", "maxpool", "spp", "dwconv3x3", "decode",
+__all__ = ["stream_ptr", "pack_input", "conv2d", "stem", "resunit", "resunit_supported", "maxpool", "spp", "dwconv3x3", "decode", "head_decode", "head_decode_supported",
            "nms_merge", "pack_conv_weight", "roundup", "run_ops"]
 
 
@@ -140,6 +140,25 @@ def decode(head, anchors_px, nc, stride_px, io, io_row_offset, p=None):
     flat = (C.c_float * (2 * na))(*[float(v) for a in anchors_px for v in a])
     check(load().yolo_decode_fwd(_ptr(head), ct, flat, na, nc, bs, ny, nx, float(stride_px), _ptr(io), io.shape[1],
                                  io_row_offset, _ptr(p), stream_ptr()), "decode")
+    return io
+
+
+def head_decode_supported(cout: int, na: int, nc: int) -> bool:
+    return bool(load().yolo_head_decode_supported(cout, na, nc))
+
+
+def head_decode(x, w_packed, bias, desc: YoloConvDesc, anchors_px, nc, stride_px, io, io_row_offset, p=None):
+    """Head conv + YOLOLayer decode in one launch (yolo_head_decode_fwd): x bf16 NHWC view described by ``desc``."""
+    _need_cuda(x, w_packed, bias, io, p)
+    na = len(anchors_px)
+    bs, ny, nx = desc.n, desc.ho, desc.wo
+    if io.dtype != torch.float32 or not io.is_contiguous() or io.shape[0] != bs or io.shape[2] != nc + 5:
+        raise RuntimeError("head_decode: io must be contiguous float32 [bs, rows, 5+nc]")
+    if p is not None and (tuple(p.shape) != (bs, na, ny, nx, nc + 5) or p.dtype != torch.float32 or not p.is_contiguous()):
+        raise RuntimeError("head_decode: p shape mismatch")
+    flat = (C.c_float * (2 * na))(*[float(v) for a in anchors_px for v in a])
+    check(load().yolo_head_decode_fwd(_ptr(x), _ptr(w_packed), _ptr(bias), C.byref(desc), flat, na, nc, float(stride_px),
+                                      _ptr(io), io.shape[1], io_row_offset, _ptr(p), stream_ptr()), "head_decode")
     return io
 
 

@@ -169,6 +169,51 @@ def test_fused_residual_unit(n, h, w, c, use_aux):
     assert float(diff.max()) <= 0.07 and float((diff > 0).float().mean()) < 0.25, (float(diff.max()), float((diff > 0).float().mean()))
 
 
+@pytest.mark.parametrize("n,h,w,cin,k,nc,act", [(2, 20, 20, 256, 1, 80, "leaky"), (3, 13, 13, 512, 1, 80, "none"),
+                                                  (1, 10, 12, 64, 3, 80, "leaky"), (2, 8, 8, 72, 1, 3, "none"),
+                                                  (1, 26, 26, 128, 1, 20, "none")])
+def test_fused_head_decode(n, h, w, cin, k, nc, act):
+    """yolo_head_decode_fwd (head conv with the YOLOLayer decode as its epilogue) against the two-launch path
+    (yolo_conv2d_fwd to an fp32 NHWC head + yolo_decode_fwd): p and io agree to fp32 summation-order noise, image
+    boundaries inside a pixel tile, 3x3 heads (YOLOv3 / Lite head 3) and small class counts are exercised."""
+    from pytorch_yolo_amd import kernels as K
+    from pytorch_yolo_amd._lib import ACT_LEAKY01, ACT_NONE, DT_F32
+    na, no = 3, nc + 5
+    cout = na * no
+    anchors = [(10., 13.), (33., 23.), (59., 119.)]
+    stride = 16.0
+    g = torch.Generator().manual_seed(h * 7 + cin)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k)) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    xin = torch.zeros(n, h, w, cin + 8, dtype=torch.bfloat16, device=DEV)
+    xin[..., 8:] = _nhwc(x)
+    wp, bp, kpad, cout_pad = K.pack_conv_weight(wt, bias, cin)
+    a = {"leaky": ACT_LEAKY01, "none": ACT_NONE}[act]
+    rows_total, row_off = na * h * w + 7, 5
+    assert K.head_decode_supported(cout, na, nc)
+    d = K.conv_desc(n=n, h=h, w=w, cin=cin, in_c_total=cin + 8, in_c_offset=8, cout=cout, out_c_total=K.roundup(cout, 8),
+                    out_c_offset=0, ksize=k, stride=1, act=a, kpad=kpad, cout_pad=cout_pad, out_dtype=DT_F32)
+    io = torch.full((n, rows_total, no), -7.0, device=DEV)
+    p = torch.full((n, na, h, w, no), -7.0, device=DEV)
+    K.head_decode(xin, wp.to(DEV), bp.to(DEV), d, anchors, nc, stride, io, row_off, p)
+    head = torch.zeros(n, h, w, K.roundup(cout, 8), device=DEV)
+    K.conv2d(xin, wp.to(DEV), bp.to(DEV), head, d)
+    io2 = torch.full((n, rows_total, no), -7.0, device=DEV)
+    p2 = torch.full((n, na, h, w, no), -7.0, device=DEV)
+    K.decode(head, anchors, nc, stride, io2, row_off, p2)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(p, p2, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(io, io2, rtol=2e-5, atol=1e-4)
+    assert torch.all(io[:, :row_off] == -7.0) and torch.all(io[:, row_off + na * h * w:] == -7.0)
+    # and against fp32 torch on the bf16-rounded operands (reference formulas, yolo_layer.py:90-96)
+    ref = F.conv2d(_bf16r(x), _bf16r(wt), bias, padding=(k - 1) // 2)
+    if act == "leaky":
+        ref = F.leaky_relu(ref, 0.1)
+    ref = ref.view(n, na, no, h, w).permute(0, 1, 3, 4, 2).contiguous()
+    torch.testing.assert_close(p.cpu(), ref, rtol=1e-4, atol=2e-4)
+
+
 @pytest.mark.parametrize("n,cin,h,w", [(2, 3, 64, 64), (1, 3, 70, 106), (1, 1, 37, 50), (2, 3, 192, 352)])
 def test_fused_stem(n, cin, h, w):
     """yolo_stem_fwd (conv3x3/s1 cin->32 + conv3x3/s2 32->64 from the float32 NCHW batch in one launch) against fp32

@@ -13,7 +13,7 @@ import torch
 import _cases as C
 from pytorch_yolo_amd import YOLOv3SPP, YOLOv3Tiny, YOLOv3TinyMobile, _lib, engine
 from pytorch_yolo_amd import kernels as K
-from pytorch_yolo_amd._lib import OP_CONV, OP_CONV1_NCHW, OP_RESUNIT, OP_STEM, OP_DWCONV, OP_MAXPOOL, OP_SPP
+from pytorch_yolo_amd._lib import OP_CONV, OP_CONV1_NCHW, OP_HEAD_DECODE, OP_RESUNIT, OP_STEM, OP_DWCONV, OP_MAXPOOL, OP_SPP
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -34,9 +34,9 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layout_matches_header():
-    # 23 int32 fields in YoloConvDesc; YoloOp = 2 int32 + 6 pointers + desc (+4 pad) + 2 pointers + 2 int32
+    # 23 int32 fields in YoloConvDesc; YoloOp = 2 int32 + 6 pointers + desc (+4 pad) + 2 pointers + 2 int32 + 9 float + 5 int32
     assert ctypes.sizeof(_lib.YoloConvDesc) == 23 * 4
-    assert ctypes.sizeof(_lib.YoloOp) == 8 + 6 * 8 + 23 * 4 + 4 + 2 * 8 + 2 * 4
+    assert ctypes.sizeof(_lib.YoloOp) == 8 + 6 * 8 + 23 * 4 + 4 + 2 * 8 + 2 * 4 + 9 * 4 + 5 * 4
     assert _lib.YoloOp.w_pre.offset == 152 and _lib.YoloOp.kpad_pre.offset == 168
     text = open(os.path.join(ROOT, "include", "yolo_hip.h")).read()
     body = text[text.index("typedef struct YoloConvDesc {"):text.index("} YoloConvDesc;")]
@@ -110,7 +110,7 @@ def test_planner_spp_fusions():
     assert ops[0].kind == OP_STEM and plan.fused_input and kinds.count(OP_STEM) == 1
     assert (ops[0].conv.h, ops[0].conv.ho, ops[0].conv.cout, ops[0].conv.res_c_total) == (640, 320, 64, 3)
     # no add / cat / upsample / pack launches; the 64-channel residual unit at 320^2 is ONE launch (yolo_resunit_fwd)
-    assert kinds.count(OP_CONV) == 72 and kinds.count(OP_RESUNIT) == 1 and kinds.count(OP_SPP) == 1 and len(ops) == 75
+    assert kinds.count(OP_CONV) == 69 and kinds.count(OP_RESUNIT) == 1 and kinds.count(OP_SPP) == 1 and len(ops) == 75
     unit = ops[kinds.index(OP_RESUNIT)]
     assert (unit.conv.cout, unit.conv.cin, unit.conv.h) == (64, 32, 320) and unit.y != unit.x and unit.w_pre and unit.bias_pre
     convs = [o for o in ops if o.kind == OP_CONV]
@@ -122,8 +122,12 @@ def test_planner_spp_fusions():
     assert [(o.conv.out_c_total, o.conv.out_c_offset) for o in ups] == [(768, 0), (384, 0)]
     spp_in = [o for o in convs if o.conv.out_c_total == 2048]
     assert len(spp_in) == 1 and spp_in[0].conv.out_c_offset == 1536                         # x lands in the last SPP slice
-    heads = [o for o in convs if o.conv.out_dtype == 1]
-    assert [(o.conv.cout, o.conv.out_c_total) for o in heads] == [(255, 256)] * 3
+    # the three detection heads decode in their conv epilogue (yolo_head_decode_fwd): no fp32 head tensor, no decode launch
+    heads = [o for o in ops if o.kind == OP_HEAD_DECODE]
+    assert [(o.conv.cout, o.conv.h, o.io_row_offset, o.io_rows_total, o.head_na, o.head_nc) for o in heads] == \
+        [(255, 20, 0, 25200, 3, 80), (255, 40, 1200, 25200, 3, 80), (255, 80, 6000, 25200, 3, 80)]
+    assert [round(o.head_stride_px) for o in heads] == [32, 16, 8] and [h["op"] is not None for h in plan.heads] == [True] * 3
+    assert list(heads[0].head_anchors_px[:6]) == [10.0, 13.0, 16.0, 30.0, 33.0, 23.0]      # anchors[i] -> head i, as the reference wires them
     assert plan.rows_total == 25200 and [h["row"] for h in plan.heads] == [0, 1200, 6000]
     assert [h["stride"] for h in plan.heads] == [32.0, 16.0, 8.0]
 
@@ -131,7 +135,7 @@ def test_planner_spp_fusions():
 def test_planner_tiny_and_mobile():
     plan = _dry_plan(YOLOv3Tiny().eval(), 416)
     kinds = [o.kind for o in _ops(plan)]
-    assert kinds.count(OP_CONV) == 13 and kinds.count(OP_MAXPOOL) == 6
+    assert kinds.count(OP_CONV) == 11 and kinds.count(OP_HEAD_DECODE) == 2 and kinds.count(OP_MAXPOOL) == 6
     pools = [o.conv for o in _ops(plan) if o.kind == OP_MAXPOOL]
     assert (pools[-1].ksize, pools[-1].stride, pools[-1].pad, pools[-1].upsample2x) == (2, 1, 1, 2)   # dilated special
     # route1 is produced straight into the concat buffer [route1(256) | upsampled(128)]
@@ -140,7 +144,7 @@ def test_planner_tiny_and_mobile():
     assert plan.rows_total == 2535 and [h["stride"] for h in plan.heads] == [16.0, 32.0]
     plan = _dry_plan(YOLOv3TinyMobile().eval(), 416)
     kinds = [o.kind for o in _ops(plan)]
-    assert kinds.count(OP_DWCONV) == 17 and kinds.count(OP_CONV) == 40 and not plan.fused_input   # stride-2 stem: generic path
+    assert kinds.count(OP_DWCONV) == 17 and kinds.count(OP_CONV) == 38 and kinds.count(OP_HEAD_DECODE) == 2 and not plan.fused_input   # stride-2 stem: generic path
     assert sum(1 for o in _ops(plan) if o.kind == OP_CONV and o.residual) == 10          # MobileNetV2 identity shortcuts
 
 

@@ -23,8 +23,8 @@ def main():
     cap = nms_capacity(plan.rows_total, 80)
     out = (torch.empty((bs, cap, 7), device=dev), torch.empty((bs, cap), dtype=torch.int32, device=dev), torch.empty((bs,), dtype=torch.int32, device=dev))
     stages = {
-        "convs": lambda: (plan.feed(x), K.run_ops(plan.op_array, plan.n_ops)),
-        "decode(3 heads)": lambda: [K.decode(hd["sym"].buf.tensor, hd["anchors"], 80, hd["stride"], io, hd["row"], p) for hd, p in zip(plan.heads, ps)],
+        "layer list": lambda: (plan.feed(x), plan._bind_outputs(io, ps), K.run_ops(plan.op_array, plan.n_ops)),
+        "decode (unfused heads)": lambda: plan._decode_unfused(io, ps),
         "nms": lambda: nms_launch(io, 0.1, 0.5, out, slot=0),
     }
     for _ in range(3):
