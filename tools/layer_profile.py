@@ -19,7 +19,8 @@ spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench
 bench = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(bench)
 from pytorch_yolo_amd import kernels as K
-from pytorch_yolo_amd._lib import OP_CONV, OP_CONV1_NCHW, OP_DWCONV, OP_MAXPOOL, OP_RESUNIT, OP_SPP, YoloOp
+from pytorch_yolo_amd._lib import (OP_CONV, OP_CONV1_NCHW, OP_DWCONV, OP_HEAD_DECODE, OP_MAXPOOL, OP_RESUNIT, OP_SPP,
+                                   OP_STEM, YoloOp)
 from pytorch_yolo_amd.utils.synthetic import synth_images, synth_state_dict
 
 
@@ -39,6 +40,7 @@ def main():
     x = synth_images(bs, wl["hw"], wl["hw"], 0).to(dev)
     plan = model.plan_for(x)
     plan.feed(x)
+    plan._bind_outputs(*plan.new_outputs())
     K.run_ops(plan.op_array, plan.n_ops)
     torch.cuda.synchronize()
     times = [[] for _ in range(plan.n_ops)]
@@ -58,16 +60,24 @@ def main():
         d = op.conv
         ms = statistics.median(times[i])
         tot_ms += ms
-        if op.kind in (OP_CONV, OP_CONV1_NCHW):
+        if op.kind == OP_STEM:
+            M = d.n * d.ho * d.wo
+            fl = 2.0 * d.n * d.h * d.w * 32 * 27 + 2.0 * M * 64 * 288
+            tot_fl += fl
+            by = d.n * d.h * d.w * 3 * 4 + M * 64 * 2
+            print(f"{i:3d} {'stem':7} {M:9d} {64:5d} {288:5d} 3 2 {ms:8.4f} {fl / ms / 1e9:8.1f} {by / ms / 1e6:7.0f}  conv1+s2")
+        elif op.kind in (OP_CONV, OP_CONV1_NCHW, OP_HEAD_DECODE):
             M, N, Kd = d.n * d.ho * d.wo, d.cout, d.ksize * d.ksize * d.cin
             fl = 2.0 * M * N * Kd
             by = d.n * d.h * d.w * d.cin * 2 + M * N * (4 if d.out_dtype else 2) * (4 if d.upsample2x else 1) + N * Kd * 2
+            if op.kind == OP_HEAD_DECODE:
+                by += M * N * 4
             if op.residual:
                 by += M * N * 2
             if op.y_aux:
                 by += M * N * 2
             tot_fl += fl
-            flags = ("res " if op.residual else "") + ("aux " if op.y_aux else "") + ("up " if d.upsample2x else "") + ("f32" if d.out_dtype else "")
+            flags = ("head+decode " if op.kind == OP_HEAD_DECODE else "") + ("res " if op.residual else "") + ("aux " if op.y_aux else "") + ("up " if d.upsample2x else "") + ("f32" if d.out_dtype else "")
             print(f"{i:3d} {'conv':7} {M:9d} {N:5d} {Kd:5d} {d.ksize:1d} {d.stride:1d} {ms:8.4f} {fl / ms / 1e9:8.1f} {by / ms / 1e6:7.0f}  {flags}")
         elif op.kind == OP_RESUNIT:
             M, Cc = d.n * d.h * d.w, d.cout
