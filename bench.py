@@ -216,7 +216,7 @@ def main():
                        "streams_per_gpu": n_streams},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                         "kernel": "conv kernels of one forward (conv_igemm_bf16 / conv3x3_halo / conv1_nchw), union over the streams",
+                         "kernel": "conv-family kernels of one forward (stem, resunit, conv_igemm_bf16 incl. head+decode, conv3x3_halo), union over the streams",
                          "flops_per_step": flops_step, "ms_per_step_conv": round(conv_ms_avg, 4)},
         }
         if not args.no_cpu_baseline and world == 1:
