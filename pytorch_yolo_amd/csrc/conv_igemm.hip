@@ -32,9 +32,14 @@ namespace {
 // the instruction's scalar offset: ~3 VALU per LDS-DMA instead of ~15.
 // LDS_EPI (bf16 output, cout % 32 == 0): the finished tile goes registers -> LDS (fp32) -> global so that
 // residual read, pre-add copy and store are 16-byte-per-lane accesses over whole channel runs.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int NS, bool FAST, bool LDS_EPI, bool MFMA16 = false, bool DECODE = false>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel(const ConvArgs a) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int NS, bool FAST, bool LDS_EPI, bool MFMA16 = false, bool DECODE = false,
+          int NP = 0>
+__global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NP)) void conv_igemm_bf16_kernel(const ConvArgs a) {
   constexpr int NW = WAVES_M * WAVES_N;
+  // NP > 0: NP extra LOADER waves issue every LDS-DMA of the block; the NW MFMA waves only read LDS and multiply
+  // (an LDS-DMA costs its issuing wave 60-180 cycles: ablation in DESIGN.md 3.1c).  NL = number of loader waves.
+  constexpr int NL = NP > 0 ? NP : NW;
+  static_assert(NP == 0 || (NS == 2 && FAST && NP % 2 == 0), "loader waves: 2-stage ring, FAST path");
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
   static_assert(BK == 32 || BK == 64, "BK");
   static_assert(NS >= 2 && NS <= 4, "ring depth");
@@ -43,8 +48,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel
   constexpr int ROWB = BK * 2;                         // bytes per LDS row
   constexpr int CPR = BK / 8;                          // 16-byte chunks per row
   constexpr int RPP = 1024 / ROWB;                     // rows per 1-KiB LDS-DMA piece (16 or 8)
-  constexpr int BNL = BN < NW * RPP ? NW * RPP : BN;   // weight rows staged (every wave issues the same count)
-  constexpr int PIT = BM / (NW * RPP), WIT = BNL / (NW * RPP);   // LDS-DMA instructions per thread per stage
+  constexpr int BNL = BN < NL * RPP ? NL * RPP : BN;   // weight rows staged (every loader issues the same count)
+  constexpr int PIT = BM / (NL * RPP), WIT = BNL / (NL * RPP);   // LDS-DMA instructions per loader thread per stage
   constexpr int LPS = PIT + WIT;
   constexpr int STAGE_B = (BM + BNL) * ROWB;
   static_assert(TM % 32 == 0 && TN % 32 == 0 && PIT >= 1 && WIT >= 1, "tile");
@@ -60,6 +65,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int lw = NP == 0 ? wave : wave - NW;            // its index among the loaders
   const YoloConvDesc& d = a.d;
 
   // XCD-aware tile order: blocks with equal blockIdx%8 share an L2; give each such group a contiguous
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel
   // piece p = it*NW + wave covers LDS rows [p*RPP, (p+1)*RPP); lane -> (row in piece, physical chunk slot).
   // swizzle: physical slot = logical chunk ^ f(row);  f = (row>>2)&3 for 64-B rows, (row>>1)&7 for 128-B rows.
   const int frow = lane / CPR;
-  const int fsw = (BK == 32) ? ((lane >> 4) & 3) : (((lane >> 4) + 4 * (wave & 1)) & 7);
+  const int fsw = (BK == 32) ? ((lane >> 4) & 3) : (((lane >> 4) + 4 * (lw & 1)) & 7);
   const int chunk = (lane & (CPR - 1)) ^ fsw;          // logical 8-channel chunk this lane fetches
   const int ntaps = d.ksize * d.ksize;
   int px_base[PIT], px_hi0[PIT], px_wi0[PIT];          // generic path
@@ -87,7 +93,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel
   const int hw_out = d.ho * d.wo;
 #pragma unroll
   for (int it = 0; it < PIT; ++it) {
-    const int m = m0 + (it * NW + wave) * RPP + frow;
+    const int m = m0 + (it * NL + lw) * RPP + frow;
     const bool ok = m < a.M;
     const int mm = ok ? m : 0;
     const int b = mm / hw_out, rem = mm - b * hw_out;
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel
   uint32_t w_off[WIT];
 #pragma unroll
   for (int it = 0; it < WIT; ++it) {
-    const int row = (it * NW + wave) * RPP + frow;
+    const int row = (it * NL + lw) * RPP + frow;
     w_off[it] = row < BN ? (uint32_t)(((n0 + row) * d.kpad + chunk * 8) * 2) : kOobOffset;
   }
   // generic: this lane's chunk has its own (tap, channel); FAST: both are wave-uniform scalars
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel
     }
   };
   auto issue = [&](int buf, int step, int lo, int hi) {
-    char* const wb = smem + buf * STAGE_B + wave * 1024;
+    char* const wb = smem + buf * STAGE_B + lw * 1024;
     char* const xb = wb + BNL * ROWB;
     if (FAST) {
       const uint32_t tap_off = (uint32_t)(((st_dh * d.w + st_dw) * d.in_c_total + kc) * 2);
@@ -144,12 +150,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel
       for (int it = 0; it < PIT; ++it) {
         if (it < lo || it >= hi) continue;
         const uint32_t voff = (px_mask[it] & bit) ? (uint32_t)px_base[it] + tap_off : kOobOffset;
-        if (!(a.debug & 1)) lds_dma16(rx, xb + it * (NW * 1024), voff);
+        if (!(a.debug & 1)) lds_dma16(rx, xb + it * (NL * 1024), voff);
       }
 #pragma unroll
       for (int it = 0; it < WIT; ++it) {
         if (PIT + it < lo || PIT + it >= hi) continue;
-        if (!(a.debug & 2)) lds_dma16s(rw, wb + it * (NW * 1024), w_off[it], (uint32_t)step * (BK * 2u));
+        if (!(a.debug & 2)) lds_dma16s(rw, wb + it * (NL * 1024), w_off[it], (uint32_t)step * (BK * 2u));
       }
     } else {
       const bool tap_ok = tap < ntaps;
@@ -159,13 +165,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel
         if (it < lo || it >= hi) continue;
         const bool ok = tap_ok && ((px_mask[it] >> (tap_ok ? tap : 0)) & 1u);
         const uint32_t voff = ok ? (uint32_t)(px_base[it] + tap_off) * 2u : kOobOffset;
-        lds_dma16(rx, xb + it * (NW * 1024), voff);
+        lds_dma16(rx, xb + it * (NL * 1024), voff);
       }
 #pragma unroll
       for (int it = 0; it < WIT; ++it) {
         if (PIT + it < lo || PIT + it >= hi) continue;
         const uint32_t voff = w_off[it] == kOobOffset ? kOobOffset : w_off[it] + (uint32_t)step * (BK * 2u);
-        lds_dma16(rw, wb + it * (NW * 1024), voff);
+        lds_dma16(rw, wb + it * (NL * 1024), voff);
       }
     }
   };
@@ -183,6 +189,26 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel
       }
     }
   };
+
+  if constexpr (NP > 0) {
+    if (wave >= NW) {
+      // ---- loader wave: stage s+1 goes out right after the barrier that frees its ring slot; the wave then sleeps
+      // in s_waitcnt / s_barrier and takes no issue slots from the MFMA waves of its SIMD
+      stage_begin();
+      issue(0, 0, 0, LPS);
+      stage_end();
+      for (int s = 0; s < a.steps; ++s) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();       // stage s landed and visible; every MFMA wave finished stage s-1
+        if (s + 1 < a.steps) {
+          stage_begin();
+          issue((s + 1) & 1, s + 1, 0, LPS);
+          stage_end();
+        }
+      }
+      return;                               // a finished wave no longer counts in the block's barriers
+    }
+  }
 
   static_assert(!MFMA16 || LDS_EPI, "the 16x16x32 path only has the LDS epilogue");
   constexpr int MI16 = MFMA16 ? TN / 16 : 1, NI16 = MFMA16 ? TM / 16 : 1;
@@ -206,6 +232,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel
   constexpr int KS = BK / 16;
 
   // prologue: NS-1 stages in flight
+  if constexpr (NP == 0) {
 #pragma unroll
   for (int p = 0; p < NS - 1; ++p)
     if (p < steps) {
@@ -213,6 +240,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel
       issue(p, p, 0, LPS);
       stage_end();
     }
+  }
 
   auto pix_of = [&](int row) -> long {
     const int pix = m0 + wm * TM + row;
@@ -222,43 +250,57 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel
   int buf = 0;
   for (int s = 0; s < steps; ++s) {
     // stage s must have landed: allow the younger stages (up to NS-2 of them) to stay in flight
-    const int younger = min(NS - 2, steps - 1 - s);
-    if (younger >= 2) wait_vmcnt<2 * LPS>();
-    else if (younger == 1) wait_vmcnt<1 * LPS>();
-    else wait_vmcnt<0>();
+    if constexpr (NP == 0) {
+      const int younger = min(NS - 2, steps - 1 - s);
+      if (younger >= 2) wait_vmcnt<2 * LPS>();
+      else if (younger == 1) wait_vmcnt<1 * LPS>();
+      else wait_vmcnt<0>();
+    }
     __builtin_amdgcn_s_barrier();   // everyone's stage s is in LDS; everyone finished reading stage s-1
-    const bool more = s + NS - 1 < steps;
+    const bool more = NP == 0 && s + NS - 1 < steps;
     int nb = buf + NS - 1;          // ring slot read in iteration s-1: free again after the barrier
     if (nb >= NS) nb -= NS;
     if (more) stage_begin();
     const char* wbuf = smem + buf * STAGE_B;
     const char* xbuf = wbuf + BNL * ROWB;
     if constexpr (MFMA16) {
-      // v_mfma_f32_16x16x32_bf16: lane = (row l&15, k-chunk l>>4); one instruction eats 32 k of a 16x16 tile
+      // v_mfma_f32_16x16x32_bf16: lane = (row l&15, k-chunk l>>4); one instruction eats 32 k of a 16x16 tile.
+      // Rows 16 apart share their swizzle term, so every fragment address is one per-lane base (two for BK 64:
+      // the second K half flips bit 6) plus a compile-time offset that goes into the ds_read immediate.
       const int c16 = lane & 15, q = lane >> 4;
+      const int rw0 = wn * TN + c16, rx0 = wm * TM + c16;
+      const int sww = (BK == 32) ? ((rw0 >> 2) & 3) : ((rw0 >> 1) & 7), swx = (BK == 32) ? ((rx0 >> 2) & 3) : ((rx0 >> 1) & 7);
+      const int wo = rw0 * ROWB + ((q ^ sww) << 4), xo = rx0 * ROWB + ((q ^ swx) << 4);
 #pragma unroll
       for (int kk = 0; kk < BK / 32; ++kk) {
         if (more) issue(nb, s + NS - 1, kk * LPS / (BK / 32), (kk + 1) * LPS / (BK / 32));
         if (!(a.debug & 4)) {
-          const int g = kk * 4 + q;
-          bf16x8 wf[MI16], xf[NI16];
+          const char* const wk = wbuf + (kk ? (wo ^ 64) : wo);
+          const char* const xk = xbuf + (kk ? (xo ^ 64) : xo);
+          bf16x8 xf[NI16];
 #pragma unroll
-          for (int i = 0; i < MI16; ++i) {
-            const int R = wn * TN + i * 16 + c16;
-            const int sw = (BK == 32) ? ((R >> 2) & 3) : ((R >> 1) & 7);
-            wf[i] = *reinterpret_cast<const bf16x8*>(wbuf + R * ROWB + ((g ^ sw) << 4));
+          for (int j = 0; j < NI16; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xk + j * 16 * ROWB);
+          if constexpr (NP > 0) {
+            // register-lean order (3 waves per SIMD leave 168 registers): weight fragments one ahead of their MFMAs
+            bf16x8 wcur = *reinterpret_cast<const bf16x8*>(wk);
+#pragma unroll
+            for (int i = 0; i < MI16; ++i) {
+              const bf16x8 wnext = *reinterpret_cast<const bf16x8*>(wk + (i + 1 < MI16 ? i + 1 : i) * 16 * ROWB);
+#pragma unroll
+              for (int j = 0; j < NI16; ++j)
+                acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wcur, xf[j], acc16[i][j], 0, 0, 0);
+              wcur = wnext;
+            }
+          } else {
+            bf16x8 wf[MI16];
+#pragma unroll
+            for (int i = 0; i < MI16; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(wk + i * 16 * ROWB);
+#pragma unroll
+            for (int i = 0; i < MI16; ++i)
+#pragma unroll
+              for (int j = 0; j < NI16; ++j)
+                acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc16[i][j], 0, 0, 0);
           }
-#pragma unroll
-          for (int j = 0; j < NI16; ++j) {
-            const int R = wm * TM + j * 16 + c16;
-            const int sw = (BK == 32) ? ((R >> 2) & 3) : ((R >> 1) & 7);
-            xf[j] = *reinterpret_cast<const bf16x8*>(xbuf + R * ROWB + ((g ^ sw) << 4));
-          }
-#pragma unroll
-          for (int i = 0; i < MI16; ++i)
-#pragma unroll
-            for (int j = 0; j < NI16; ++j)
-              acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc16[i][j], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -457,7 +499,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_bf16_kernel
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int NS, bool FAST, bool LDS_EPI, bool MFMA16 = false, bool DECODE = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int NS, bool FAST, bool LDS_EPI, bool MFMA16 = false, bool DECODE = false,
+          int NP = 0>
 int launch_cfg(const ConvArgs& a, hipStream_t s) {
   const int m_tiles = (a.M + BM - 1) / BM;
   ConvArgs b = a;
@@ -465,8 +508,8 @@ int launch_cfg(const ConvArgs& a, hipStream_t s) {
   b.steps = (a.d.ksize * a.d.ksize * a.d.cin + BK - 1) / BK;   // kpad >= steps*BK: the K tail is zero-padded
   const long grid = (long)m_tiles * b.n_tiles;
   if (grid > 0x7fffffffL) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv grid too large");
-  hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, BK, NS, FAST, LDS_EPI, MFMA16, DECODE>), dim3((unsigned)grid),
-                     dim3(64 * WAVES_M * WAVES_N), 0, s, b);
+  hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, BK, NS, FAST, LDS_EPI, MFMA16, DECODE, NP>), dim3((unsigned)grid),
+                     dim3(64 * (WAVES_M * WAVES_N + NP)), 0, s, b);
   return yolo_check_launch("yolo_conv2d_fwd");
 }
 
@@ -566,9 +609,13 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
   // it: +2..3 % measured on every shape).  YOLO_CONV_DEBUG bit 2048 falls back to 32x32x16.
   if (epi && !(conv_debug_flags & 2048)) {
     switch (pick) {
-      case 5: return launch_cfg<256, 256, 4, 2, 64, 2, true, true, true>(a, s);
+      case 5: return launch_cfg<256, 256, 4, 2, 64, 2, true, true, true>(a, s);   // (with loader waves it spills: 128 acc + 3 waves/SIMD)
       case 3: return launch_cfg<256, 128, 4, 2, 64, 2, true, true, true>(a, s);
-      case 12: return launch_cfg<128, 256, 2, 4, 64, 2, true, true, true>(a, s);
+      case 12:
+        // 3x3 layers: four extra loader waves issue all LDS-DMA, the eight MFMA waves only read LDS and multiply
+        // (-7 % on the 20x20 layers; neutral on 1x1, so those keep the symmetric form).  Bit 256 disables it.
+        if (d.ksize == 3 && !(conv_debug_flags & 256)) return launch_cfg<128, 256, 2, 4, 64, 2, true, true, true, false, 4>(a, s);
+        return launch_cfg<128, 256, 2, 4, 64, 2, true, true, true>(a, s);
       case 9: return launch_cfg<256, 128, 4, 2, 32, 2, true, true, true>(a, s);
       case 11: return launch_cfg<64, 64, 2, 2, 64, 2, true, true, true>(a, s);
       default: return launch_cfg<128, 128, 2, 2, 64, 2, true, true, true>(a, s);
