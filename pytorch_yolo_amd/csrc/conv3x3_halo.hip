@@ -330,8 +330,12 @@ int yolo_conv::launch_halo3x3(const ConvArgs& a, hipStream_t s) {
   if ((double)d.h * d.w < 0.85 * 256.0 * tiles || (long)d.h * d.w < 80 * 80) return 1;
   if (d.cin % 64 == 0) {
     const bool one = d.cin == 64;
-    if (d.cout % 256 == 0 && !(a.debug & 512)) return one ? launch<16, 16, 256, 4, 2, 64, 1>(a, s) : launch<16, 16, 256, 4, 2, 64, 2>(a, s);
-    if (d.cout % 128 == 0) return one ? launch<16, 16, 128, 4, 2, 64, 1>(a, s) : launch<16, 16, 128, 4, 2, 64, 2>(a, s);
+    // 128 couts per block with ONE halo buffer = 73 KB of LDS, i.e. two blocks per CU: they drift apart, so one
+    // block's epilogue (a third of a layer's time on the 80x80 maps) runs under the other's MFMA loop.  Measured
+    // -12..-14 % per layer against 256 couts per block (146 KB, one block per CU); YOLO_CONV_DEBUG bit 1024 selects
+    // the old form.  (128 couts with two halo buffers, 114 KB, is the worst of the three.)
+    if (d.cout % 256 == 0 && (a.debug & 1024)) return one ? launch<16, 16, 256, 4, 2, 64, 1>(a, s) : launch<16, 16, 256, 4, 2, 64, 2>(a, s);
+    if (d.cout % 128 == 0) return launch<16, 16, 128, 4, 2, 64, 1>(a, s);
     return one ? launch<16, 16, 64, 4, 1, 64, 1>(a, s) : launch<16, 16, 64, 4, 1, 64, 2>(a, s);
   }
   const bool one = d.cin == 32;
