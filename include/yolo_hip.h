@@ -160,6 +160,18 @@ YOLO_API int yolo_nms_merge(float* pred, int bs, int rows, int nc, float conf_th
 YOLO_API int yolo_scale_coords(float* dets, int bs, int cap, int row_floats, const float* params_dev, int do_round,
                                yolo_stream_t s);
 
+/* ---- pre-processing of one decoded image: LetterBox (utils/augs.py:7-94: cv2.resize
+ *  INTER_AREA by resize_ratio to rh x rw, placed at (top,left) of a th x tw rectangle with BORDER_REPLICATE) and,
+ *  when dst_f32 is given, _convert_img_for_net + equalize_shapes as well (utils/dataset_csv.py:79-87,146-171:
+ *  float32 /255, HWC -> CHW, the rectangle at (off_y,off_x) of a dst_h x dst_w canvas filled with `fill` = 0.5).
+ *  src: uint8 [h,w,c] interleaved, c <= 4, row pitch src_pitch bytes.  Exactly one destination:
+ *  dst_u8 [th,tw,c] (= LetterBox.apply's image) or dst_f32 [c,dst_h,dst_w] (one image of the NCHW batch).
+ *  The geometry (rh, rw, pads) is computed by the caller exactly as LetterBox.update_params does (augs.py:24-63;
+ *  pytorch_yolo_amd.utils.augs.letterbox_params).  cv2 is not available to pin the resize: see oracle/preprocess.py. */
+YOLO_API int yolo_letterbox_u8_fwd(const uint8_t* src, int h, int w, int c, int src_pitch, double resize_ratio, int rh,
+                                   int rw, int top, int left, int th, int tw, uint8_t* dst_u8, float* dst_f32,
+                                   int dst_h, int dst_w, int off_y, int off_x, float fill, yolo_stream_t s);
+
 /* ---- batched launcher: run a recorded list of ops with one FFI crossing (host overhead only). */
 enum { YOLO_OP_CONV = 1, YOLO_OP_MAXPOOL = 2, YOLO_OP_SPP = 3, YOLO_OP_DWCONV = 4, YOLO_OP_CONV1_NCHW = 5,
        YOLO_OP_RESUNIT = 6, YOLO_OP_STEM = 7, YOLO_OP_HEAD_DECODE = 8 };

@@ -61,6 +61,8 @@ SIGNATURES = {
     "yolo_nms_merge": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [C.c_float] * 3 + [C.c_int] * 2 +
                        [C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "yolo_scale_coords": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "yolo_letterbox_u8_fwd": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_double] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p] +
+                              [C.c_int] * 4 + [C.c_float, C.c_void_p]),
     "yolo_run_ops": (C.c_int, [C.POINTER(YoloOp), C.c_int, C.c_void_p]),
 }
 

@@ -22,6 +22,7 @@ SOURCES = {
     "conv_resunit.hip": [],
     "conv_stem.hip": [],
     "pointwise.hip": [],
+    "preprocess.hip": ["-ffp-contract=off"],
     "nms.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
@@ -37,7 +38,8 @@ def _stale(out: str, deps) -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_common.h"),
-               os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "yolo_hip.h")]
+               os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "yolo_hip.h"),
+               os.path.abspath(__file__)]        # per-file flags live here: a flag change rebuilds too
     objs = []
     for src, extra in SOURCES.items():
         s = os.path.join(CSRC, src)

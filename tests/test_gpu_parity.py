@@ -607,3 +607,41 @@ def test_pipelined_gather_matches_joined_gather():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("h,w,c,new_shape", [(60, 100, 3, 64), (100, 60, 3, 64), (97, 131, 3, 96), (48, 48, 1, 96),
+                                             (90, 120, 3, (64, 64)), (33, 200, 4, 128)])
+def test_letterbox_vs_oracle(h, w, c, new_shape):
+    """yolo_letterbox_u8_fwd (LetterBox, reference utils/augs.py:7-94): the uint8 letterboxed image equals the
+    oracle's bit for bit (same float32 operation order), for non-integer / integer down-scaling, up-scaling,
+    1..4 channels and fixed-shape targets."""
+    from oracle import preprocess as O
+    from pytorch_yolo_amd.utils.augs import LetterBox
+    rng = np.random.default_rng(h * 1000 + w)
+    img = rng.integers(0, 256, (h, w, c), dtype=np.uint8)
+    want, p = O.letterbox(img, new_shape)
+    t = LetterBox(new_shape)
+    got = t(image=torch.from_numpy(img).to(DEV))["image"].cpu().numpy()
+    assert t.params == p and got.shape == want.shape
+    assert np.array_equal(got, want)
+
+
+def test_preprocess_batch_vs_oracle():
+    """LetterBox + /255 + HWC->CHW + equalize_shapes fused (one launch per image) == the oracle's composition of
+    the reference steps, exactly; then the batch goes through detect() like any other input."""
+    from oracle import preprocess as O
+    from pytorch_yolo_amd.utils.augs import preprocess_batch
+    rng = np.random.default_rng(11)
+    imgs = [rng.integers(0, 256, s, dtype=np.uint8) for s in ((60, 100, 3), (100, 60, 3), (64, 64, 3), (50, 111, 3))]
+    want, wmeta = O.preprocess_batch(imgs, 64)
+    got, meta = preprocess_batch([torch.from_numpy(i).to(DEV) for i in imgs], 64)
+    assert tuple(got.shape) == want.shape and meta == wmeta
+    assert np.array_equal(got.cpu().numpy(), want)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        preprocess_batch([torch.from_numpy(imgs[0])], 64)
+    case = C.MODEL_CASES["tiny_small"]
+    model, sd, _ = build_case(case)
+    model = model.to(DEV)
+    with torch.no_grad():
+        io, _ = model(got)
+    assert io.shape[0] == len(imgs) and bool(torch.isfinite(io).all())
