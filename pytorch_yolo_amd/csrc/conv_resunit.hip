@@ -114,11 +114,17 @@ __global__ __launch_bounds__(512) void resunit_kernel(const ResUnitArgs ra) {
         for (int e = 0; e < 16; ++e) acc1[p][i][e] = 0.f;
 
     issue_a(0, 0);
+    issue_a(1, 1);                            // both ring slots are empty: two K steps go out together (A_STEPS >= 2)
 #pragma unroll 1
     for (int step = 0; step < A_STEPS; ++step) {
-      wait_vmcnt<0>();
+      if (step == 0) {                        // stage 1 may stay in flight (3 x pieces, +1 W1 piece on the first waves)
+        if (wave < A_WPIECES) wait_vmcnt<A_XPT + 1>();
+        else wait_vmcnt<A_XPT>();
+      } else {
+        wait_vmcnt<0>();
+      }
       __builtin_amdgcn_s_barrier();
-      if (step + 1 < A_STEPS) issue_a((step + 1) & 1, step + 1);
+      if (step >= 1 && step + 1 < A_STEPS) issue_a((step + 1) & 1, step + 1);
       const char* const xb = s_ring + (step & 1) * A_STAGE;
       const char* const wbuf = xb + A_XB;
 #pragma unroll
