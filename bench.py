@@ -108,6 +108,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # rehearsal on a one-GPU box only: YOLO_BENCH_REHEARSE=1 puts every rank on cuda:0 and uses gloo (RCCL refuses two
+    # ranks on one device); the numbers of such a run mean nothing, it exercises the sharded control flow
+    rehearse = os.environ.get("YOLO_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # under torch.distributed.run (RANK set) the sharded path runs even with one rank, so that it can be rehearsed
@@ -115,7 +120,10 @@ def main():
     sharded = world > 1 or ("RANK" in os.environ and os.environ.get("YOLO_BENCH_SHARDED_AT_1") == "1")
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     wl = WORKLOADS[args.workload]
     bs = args.bs or wl["bs"]
