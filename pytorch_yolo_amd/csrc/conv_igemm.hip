@@ -40,7 +40,7 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NP)) void conv_igemm_bf16
   // (an LDS-DMA costs its issuing wave 60-180 cycles: ablation in DESIGN.md 3.1c).  NL = number of loader waves.
   constexpr int NL = NP > 0 ? NP : NW;
   static_assert(NP == 0 || (NS == 2 && FAST && NP % 2 == 0), "loader waves: 2-stage ring, FAST path");
-  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves");
   static_assert(BK == 32 || BK == 64, "BK");
   static_assert(NS >= 2 && NS <= 4, "ring depth");
   constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N;  // per-wave tile (pixels x couts)
@@ -609,8 +609,13 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
   // it: +2..3 % measured on every shape).  YOLO_CONV_DEBUG bit 2048 falls back to 32x32x16.
   if (epi && !(conv_debug_flags & 2048)) {
     switch (pick) {
-      case 5: return launch_cfg<256, 256, 4, 2, 64, 2, true, true, true>(a, s);   // (with loader waves it spills: 128 acc + 3 waves/SIMD)
+      case 5:
+        // 16 waves (64x64 each) instead of 8 (64x128): four waves per SIMD hide the LDS-DMA issue stalls of one another
+        // (-7..8 % per layer; loader waves would spill here: 128 accumulators + 3 waves per SIMD).  Bit 512: old form.
+        if (conv_debug_flags & 512) return launch_cfg<256, 256, 4, 2, 64, 2, true, true, true>(a, s);
+        return launch_cfg<256, 256, 4, 4, 64, 2, true, true, true>(a, s);
       case 3: return launch_cfg<256, 128, 4, 2, 64, 2, true, true, true>(a, s);
+      case 13: return launch_cfg<256, 256, 4, 4, 64, 2, true, true, true>(a, s);
       case 12:
         // 3x3 layers: four extra loader waves issue all LDS-DMA, the eight MFMA waves only read LDS and multiply
         // (-7 % on the 20x20 layers; neutral on 1x1, so those keep the symmetric form).  Bit 256 disables it.
