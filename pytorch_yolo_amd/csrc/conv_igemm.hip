@@ -620,6 +620,7 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
         // 3x3 layers: four extra loader waves issue all LDS-DMA, the eight MFMA waves only read LDS and multiply
         // (-7 % on the 20x20 layers; neutral on 1x1, so those keep the symmetric form).  Bit 256 disables it.
         if (d.ksize == 3 && !(conv_debug_flags & 256)) return launch_cfg<128, 256, 2, 4, 64, 2, true, true, true, false, 4>(a, s);
+        if (d.ksize == 1) return launch_cfg<128, 256, 2, 8, 64, 2, true, true, true>(a, s);   // 16 waves: -7..12 % on the 40x40 1x1 layers
         return launch_cfg<128, 256, 2, 4, 64, 2, true, true, true>(a, s);
       case 9: return launch_cfg<256, 128, 4, 2, 32, 2, true, true, true>(a, s);
       case 11: return launch_cfg<64, 64, 2, 2, 64, 2, true, true, true>(a, s);
