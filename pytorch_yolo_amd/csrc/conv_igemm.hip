@@ -572,6 +572,8 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
   a.debug = conv_debug_flags;
   if (hd) {   // head conv with the YOLOLayer decode as its epilogue: one 64-pixel x 256-cout tile per block
     a.hd = *hd;
+    // 8 waves (2 blocks per CU -> 4 per SIMD) when cin allows 64-deep stages; bit 8192 selects the 4-wave forms
+    if (d.cin % 64 == 0 && !(conv_debug_flags & 8192)) return launch_cfg<64, 256, 1, 8, 64, 2, true, false, false, true>(a, s);
     return d.cin % 32 == 0 ? launch_cfg<64, 256, 1, 4, 32, 2, true, false, false, true>(a, s)
                            : launch_cfg<64, 256, 1, 4, 32, 2, false, false, false, true>(a, s);
   }
@@ -624,7 +626,9 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
         return launch_cfg<128, 256, 2, 4, 64, 2, true, true, true>(a, s);
       case 9: return launch_cfg<256, 128, 4, 2, 32, 2, true, true, true>(a, s);
       case 11: return launch_cfg<64, 64, 2, 2, 64, 2, true, true, true>(a, s);
-      default: return launch_cfg<128, 128, 2, 2, 64, 2, true, true, true>(a, s);
+      default:
+        if (conv_debug_flags & 8192) return launch_cfg<128, 128, 2, 2, 64, 2, true, true, true>(a, s);
+        return launch_cfg<128, 128, 2, 4, 64, 2, true, true, true>(a, s);   // 8 waves of 64x32: -13 % on the stride-2 64->128 layer
     }
   }
   switch (pick) {
