@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NP)) void conv_igemm_bf16
   // NP > 0: NP extra LOADER waves issue every LDS-DMA of the block; the NW MFMA waves only read LDS and multiply
   // (an LDS-DMA costs its issuing wave 60-180 cycles: ablation in DESIGN.md 3.1c).  NL = number of loader waves.
   constexpr int NL = NP > 0 ? NP : NW;
-  static_assert(NP == 0 || (NS == 2 && FAST && NP % 2 == 0), "loader waves: 2-stage ring, FAST path");
+  static_assert(NP == 0 || (NS <= 3 && FAST && NP % 2 == 0), "loader waves: 2- or 3-stage ring, FAST path");
   static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves");
   static_assert(BK == 32 || BK == 64, "BK");
   static_assert(NS >= 2 && NS <= 4, "ring depth");
@@ -194,17 +194,24 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NP)) void conv_igemm_bf16
     if (wave >= NW) {
       // ---- loader wave: stage s+1 goes out right after the barrier that frees its ring slot; the wave then sleeps
       // in s_waitcnt / s_barrier and takes no issue slots from the MFMA waves of its SIMD
-      stage_begin();
-      issue(0, 0, 0, LPS);
-      stage_end();
-      for (int s = 0; s < a.steps; ++s) {
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();       // stage s landed and visible; every MFMA wave finished stage s-1
-        if (s + 1 < a.steps) {
+#pragma unroll
+      for (int p = 0; p < NS - 1; ++p)        // prologue: NS-1 stages in flight
+        if (p < a.steps) {
           stage_begin();
-          issue((s + 1) & 1, s + 1, 0, LPS);
+          issue(p, p, 0, LPS);
           stage_end();
         }
+      int slot = NS - 1;                      // ring slot of the next stage to issue
+      for (int s = 0; s < a.steps; ++s) {
+        if (NS == 3 && s + 1 < a.steps) wait_vmcnt<LPS>();     // stage s landed; stage s+1 may stay in flight
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();       // stage s landed and visible; every MFMA wave finished stage s-1
+        if (s + NS - 1 < a.steps) {
+          stage_begin();
+          issue(slot, s + NS - 1, 0, LPS);  // into the slot stage s-1 was read from
+          stage_end();
+        }
+        if (++slot == NS) slot = 0;
       }
       return;                               // a finished wave no longer counts in the block's barriers
     }
@@ -621,10 +628,14 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
       case 12:
         // 3x3 layers: four extra loader waves issue all LDS-DMA, the eight MFMA waves only read LDS and multiply
         // (-7 % on the 20x20 layers; neutral on 1x1, so those keep the symmetric form).  Bit 256 disables it.
+        // ... and a THREE-stage ring: a K step of this tile is ~0.9 us of MFMA, less than an HBM round trip, and in the
+        // model the weights of these layers (9.4 MB each) come from HBM: 0.094 -> 0.075 ms per layer inside the network
+        // (nothing in a back-to-back micro-benchmark, where they sit in the Infinity Cache).  Bit 16384: two stages.
+        if (d.ksize == 3 && !(conv_debug_flags & (256 | 16384))) return launch_cfg<128, 256, 2, 4, 64, 3, true, true, true, false, 4>(a, s);
         if (d.ksize == 3 && !(conv_debug_flags & 256)) return launch_cfg<128, 256, 2, 4, 64, 2, true, true, true, false, 4>(a, s);
-        if (d.ksize == 1) return launch_cfg<128, 256, 2, 8, 64, 2, true, true, true>(a, s);   // 16 waves: -7..12 % on the 40x40 1x1 layers
+        if (d.ksize == 1) return launch_cfg<128, 256, 2, 8, 64, 3, true, true, true>(a, s);   // 16 waves (-7..12 % on the 40x40 1x1 layers), 3 stages
         return launch_cfg<128, 256, 2, 4, 64, 2, true, true, true>(a, s);
-      case 9: return launch_cfg<256, 128, 4, 2, 32, 2, true, true, true>(a, s);
+      case 9: return launch_cfg<256, 128, 4, 2, 32, 2, true, true, true>(a, s);   // (a third stage costs a resident block: slower)
       case 11: return launch_cfg<64, 64, 2, 2, 64, 2, true, true, true>(a, s);
       default:
         if (conv_debug_flags & 8192) return launch_cfg<128, 128, 2, 2, 64, 2, true, true, true>(a, s);
