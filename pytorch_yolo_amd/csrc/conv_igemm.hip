@@ -636,7 +636,12 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
         if (d.ksize == 1) return launch_cfg<128, 256, 2, 8, 64, 3, true, true, true>(a, s);   // 16 waves (-7..12 % on the 40x40 1x1 layers), 3 stages
         return launch_cfg<128, 256, 2, 4, 64, 2, true, true, true>(a, s);
       case 9: return launch_cfg<256, 128, 4, 2, 32, 2, true, true, true>(a, s);   // (a third stage costs a resident block: slower)
-      case 11: return launch_cfg<64, 64, 2, 2, 64, 2, true, true, true>(a, s);
+      case 11:
+        // inside the network (weights from HBM) an 8-wave 128x128 tile with a three-stage ring edges out the 64x64
+        // tiles that win a back-to-back micro-benchmark; layers with fewer than 64 such tiles keep the small ones
+        if (((M + 127) / 128) * ((d.cout + 127) / 128) >= 64 && !(conv_debug_flags & 32768))
+          return launch_cfg<128, 128, 2, 4, 64, 3, true, true, true>(a, s);
+        return launch_cfg<64, 64, 2, 2, 64, 2, true, true, true>(a, s);
       default:
         if (conv_debug_flags & 8192) return launch_cfg<128, 128, 2, 2, 64, 2, true, true, true>(a, s);
         return launch_cfg<128, 128, 2, 4, 64, 2, true, true, true>(a, s);   // 8 waves of 64x32: -13 % on the stride-2 64->128 layer
