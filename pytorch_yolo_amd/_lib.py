@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libyolo_hip.so")
+LIB_PATH = os.environ.get("YOLO_HIP_LIB") or os.path.join(_HERE, "csrc", "libyolo_hip.so")   # override: A/B runs of two builds
 
 ACT_NONE, ACT_LEAKY01, ACT_RELU6 = 0, 1, 2
 DT_BF16, DT_F32 = 0, 1

@@ -64,82 +64,84 @@ __device__ __forceinline__ void lds_dma16s(__amdgpu_buffer_rsrc_t rsrc, char* ld
 // the output pixel index (n*ho*wo order) or -1.  `stg` = private per-wave LDS slab of TM*kEpiPitch bytes.
 constexpr int kEpiPitch = 144;   // 32 f32 + 16 B pad
 
-// Residual tile prefetched into registers during the last K steps (same lane mapping as the coalesced phase),
-// so the read overlaps the MFMAs instead of extending the epilogue.
+// Residual values handed to the epilogue in registers instead of being read from global there (conv_resunit.hip
+// takes them from its LDS staging).  Flat order = the order the coalesced phase consumes them in.
 template <int MI, int TM>
 struct ResPrefetch {
-  bf16x8 v[MI][TM / 16];
+  bf16x8 v[MI * (TM / 16)];
 };
 
-template <int MI, int TM, typename PixOf>
-__device__ __forceinline__ void prefetch_residual(const ConvArgs& a, ResPrefetch<MI, TM>& r, int lane, int cout0,
-                                                  PixOf pix_of) {
-  const YoloConvDesc& d = a.d;
-  const int crow = lane >> 2, cchunk = lane & 3;
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int cbase = cout0 + i * 32;
-#pragma unroll
-    for (int pass = 0; pass < TM / 16; ++pass) {
-      const long pix = pix_of(pass * 16 + crow);
-      if (pix >= 0 && cbase < d.cout)
-        r.v[i][pass] = *reinterpret_cast<const bf16x8*>(a.res + pix * d.res_c_total + d.res_c_offset + cbase + cchunk * 8);
-    }
-  }
-}
-
-// Core of the LDS-staged epilogue: write_slab(i) puts act(acc + bias) of 32-cout slab i as fp32 into the wave's
-// private slab [TM pixel rows][32 couts] (row pitch kEpiPitch); the coalesced phase below is layout-agnostic.
-template <int MI, int TM, typename WriteSlab, typename PixOf>
-__device__ __forceinline__ void epilogue_lds_core(const ConvArgs& a, char* stg, int lane, int cout0, WriteSlab write_slab,
+// Core of the LDS-staged epilogue.  write_rows(i, cbase, row_lo, nrows, pitch, col_off) puts act(acc + bias) of
+// 32-cout slab i, pixel rows [row_lo, row_lo + nrows) of the wave's tile, as fp32 at
+// stg + (row - row_lo) * pitch + col_off (+ 4 * cout within the slab).
+// PAIRED form (MI even): two slabs = 64 couts are staged side by side for HALF the rows at a time (same LDS
+// footprint), so that in the coalesced phase eight lanes cover one pixel's 64 couts: every store instruction
+// writes whole 128-byte lines.  With one 32-cout slab at a time a line was written as two 64-byte halves in two
+// different passes, and the partially written lines cost the memory system about twice the traffic of the store.
+constexpr int kEpiPitch2 = 272;   // 64 f32 + 16 B pad
+template <int MI, int TM, typename WriteRows, typename PixOf>
+__device__ __forceinline__ void epilogue_lds_core(const ConvArgs& a, char* stg, int lane, int cout0, WriteRows write_rows,
                                                   PixOf pix_of, const ResPrefetch<MI, TM>* rpre) {
   const YoloConvDesc& d = a.d;
-  const int crow = lane >> 2, cchunk = lane & 3;   // coalesced phase: 16 pixel rows x 4 chunks of 8 couts
   const int hw_out = d.ho * d.wo;
+  constexpr bool PAIR = MI % 2 == 0;
+  static_assert(!PAIR || (TM / 2) * kEpiPitch2 <= TM * kEpiPitch, "paired staging must fit the slab");
+  constexpr int LPP = PAIR ? 8 : 4;                  // lanes per pixel in the coalesced phase
+  constexpr int RPI = 64 / LPP;                      // pixel rows per store instruction
+  constexpr int PITCH = PAIR ? kEpiPitch2 : kEpiPitch;
+  constexpr int HALVES = PAIR ? 2 : 1, HROWS = TM / HALVES;
+  const int crow = lane / LPP, cchunk = lane % LPP;
+  int rp_idx = 0;
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int cbase = cout0 + i * 32;              // first cout of this slab
-    if (cbase >= d.cout) continue;                 // cout % 32 == 0: a slab is all-or-nothing
-    write_slab(i, cbase);
-    __builtin_amdgcn_wave_barrier();               // LDS ops of one wave execute in order
-    const long cofs = cbase + cchunk * 8;
+  for (int ig = 0; ig < (PAIR ? MI / 2 : MI); ++ig) {
+    const int cbase = cout0 + ig * (PAIR ? 64 : 32);   // first cout of this group
+    if (cbase >= d.cout) continue;                     // cout % 32 == 0: a slab is all-or-nothing
+    const bool second = PAIR && cbase + 32 < d.cout;   // the group's second slab exists
 #pragma unroll
-    for (int pass = 0; pass < TM / 16; ++pass) {
-      const int row = pass * 16 + crow;
-      const long pix = pix_of(row);
-      if (pix >= 0) {
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * kEpiPitch + cchunk * 32);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * kEpiPitch + cchunk * 32 + 16);
-        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        if (a.aux) {
+    for (int h = 0; h < HALVES; ++h) {
+      write_rows(PAIR ? 2 * ig : ig, cbase, h * HROWS, HROWS, PITCH, 0);
+      if (second) write_rows(2 * ig + 1, cbase + 32, h * HROWS, HROWS, PITCH, 128);
+      __builtin_amdgcn_wave_barrier();               // LDS ops of one wave execute in order
+      const long cofs = cbase + cchunk * 8;
+      const bool chunk_ok = cbase + cchunk * 8 < d.cout;
+#pragma unroll
+      for (int pass = 0; pass < HROWS / RPI; ++pass, ++rp_idx) {
+        const int lrow = pass * RPI + crow;
+        const long pix = pix_of(h * HROWS + lrow);
+        if (pix >= 0 && chunk_ok) {
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + lrow * PITCH + cchunk * 32);
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + lrow * PITCH + cchunk * 32 + 16);
+          float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          if (a.aux) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+            *reinterpret_cast<bf16x8*>(a.aux + pix * d.aux_c_total + d.aux_c_offset + cofs) = o;
+          }
+          if (a.res) {
+            const bf16x8 rv = rpre ? rpre->v[rp_idx]
+                                   : *reinterpret_cast<const bf16x8*>(a.res + pix * d.res_c_total + d.res_c_offset + cofs);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+          }
           bf16x8 o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-          *reinterpret_cast<bf16x8*>(a.aux + pix * d.aux_c_total + d.aux_c_offset + cofs) = o;
-        }
-        if (a.res) {
-          const bf16x8 rv = rpre ? rpre->v[i][pass]
-                                 : *reinterpret_cast<const bf16x8*>(a.res + pix * d.res_c_total + d.res_c_offset + cofs);
+          bf16_t* const ybase = reinterpret_cast<bf16_t*>(a.y) + d.out_c_offset + cofs;
+          if (d.upsample2x) {
+            const int b = (int)(pix / hw_out), rem = (int)(pix - (long)b * hw_out);
+            const int oh = rem / d.wo, ow = rem - oh * d.wo;
+            const long op = ((long)(b * 2 * d.ho + 2 * oh)) * (2 * d.wo) + 2 * ow;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
-        }
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-        bf16_t* const ybase = reinterpret_cast<bf16_t*>(a.y) + d.out_c_offset + cofs;
-        if (d.upsample2x) {
-          const int b = (int)(pix / hw_out), rem = (int)(pix - (long)b * hw_out);
-          const int oh = rem / d.wo, ow = rem - oh * d.wo;
-          const long op = ((long)(b * 2 * d.ho + 2 * oh)) * (2 * d.wo) + 2 * ow;
-#pragma unroll
-          for (int rep = 0; rep < 4; ++rep)
-            *reinterpret_cast<bf16x8*>(ybase + (op + (rep >> 1) * 2 * d.wo + (rep & 1)) * d.out_c_total) = o;
-        } else {
-          *reinterpret_cast<bf16x8*>(ybase + pix * d.out_c_total) = o;
+            for (int rep = 0; rep < 4; ++rep)
+              *reinterpret_cast<bf16x8*>(ybase + (op + (rep >> 1) * 2 * d.wo + (rep & 1)) * d.out_c_total) = o;
+          } else {
+            *reinterpret_cast<bf16x8*>(ybase + pix * d.out_c_total) = o;
+          }
         }
       }
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -149,9 +151,11 @@ template <int MI, int NI, int TM, typename PixOf>
 __device__ __forceinline__ void epilogue_lds(const ConvArgs& a, const f32x16 (&acc)[MI][NI], char* stg, int lane,
                                              int cout0, PixOf pix_of, const ResPrefetch<MI, TM>* rpre = nullptr) {
   const int r32 = lane & 31, khalf = lane >> 5;
-  epilogue_lds_core<MI, TM>(a, stg, lane, cout0, [&](int i, int cbase) {
+  epilogue_lds_core<MI, TM>(a, stg, lane, cout0, [&](int i, int cbase, int row_lo, int nrows, int pitch, int col_off) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
+      const int row = j * 32 + r32 - row_lo;
+      if (row < 0 || row >= nrows) continue;
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int cl = g4 * 8 + khalf * 4;
@@ -159,7 +163,7 @@ __device__ __forceinline__ void epilogue_lds(const ConvArgs& a, const f32x16 (&a
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[i][j][g4 * 4 + e] + bv[e], a.d.act);
-        *reinterpret_cast<f32x4*>(stg + (j * 32 + r32) * kEpiPitch + cl * 4) = v;
+        *reinterpret_cast<f32x4*>(stg + row * pitch + col_off + cl * 4) = v;
       }
     }
   }, pix_of, rpre);
@@ -171,17 +175,19 @@ template <int MI, int NI16, int TM, typename PixOf>
 __device__ __forceinline__ void epilogue_lds16(const ConvArgs& a, const f32x4 (&acc)[2 * MI][NI16], char* stg, int lane,
                                                int cout0, PixOf pix_of) {
   const int c16 = lane & 15, q = lane >> 4;
-  epilogue_lds_core<MI, TM>(a, stg, lane, cout0, [&](int i, int cbase) {
+  epilogue_lds_core<MI, TM>(a, stg, lane, cout0, [&](int i, int cbase, int row_lo, int nrows, int pitch, int col_off) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int cl = t * 16 + q * 4;
       const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + cbase + cl);
 #pragma unroll
       for (int j = 0; j < NI16; ++j) {
+        const int row = j * 16 + c16 - row_lo;
+        if (row < 0 || row >= nrows) continue;
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[2 * i + t][j][e] + bv[e], a.d.act);
-        *reinterpret_cast<f32x4*>(stg + (j * 16 + c16) * kEpiPitch + cl * 4) = v;
+        *reinterpret_cast<f32x4*>(stg + row * pitch + col_off + cl * 4) = v;
       }
     }
   }, pix_of, (const ResPrefetch<MI, TM>*)nullptr);

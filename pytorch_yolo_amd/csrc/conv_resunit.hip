@@ -56,6 +56,9 @@ __global__ __launch_bounds__(512) void resunit_kernel(const ResUnitArgs ra) {
   static_assert(C == 64 || C == 128 || C == 256, "C");
   static_assert((WPIECES % NW == 0 || WPIECES < NW) && A_WPIECES <= NW, "pieces");
   static_assert(LDS_B <= 160 * 1024, "LDS");
+  // when all 9 * NCH tap slices of W2 fit the (now idle) phase-A staging region they are fetched in one go: one
+  // load latency for phase B instead of one per tap, and no barriers inside the tap loop
+  constexpr bool ALLW = 9 * NCH * WBUF_B <= RING_B;
 
   __shared__ __attribute__((aligned(16))) char smem[LDS_B];
   char* const s_mid = smem;
@@ -82,6 +85,12 @@ __global__ __launch_bounds__(512) void resunit_kernel(const ResUnitArgs ra) {
   const __amdgpu_buffer_rsrc_t rw1 = __builtin_amdgcn_make_buffer_rsrc((void*)ra.w1, 0, ra.w1_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
 
+  // C = 64: the residual (= the tile's own x pixels) is picked out of the phase-A staging while it is still in LDS —
+  // both K steps of x are resident then — instead of being re-read from global in the epilogue, where four
+  // dependent load -> add -> store rounds per wave were half of this kernel's time (ablation in DESIGN.md 3.1d)
+  ResPrefetch<MI, TM> rp;
+  constexpr bool RES_FROM_LDS = C == 64;
+
   // ================================ phase A: mid = act(W1 . x_halo + b1) ================================
   {
     const int frow = lane >> 2;                                    // 16 rows x 4 sixteen-byte chunks per piece
@@ -99,7 +108,8 @@ __global__ __launch_bounds__(512) void resunit_kernel(const ResUnitArgs ra) {
     auto issue_a = [&](int st, int step) {
       char* const base = s_ring + st * A_STAGE;
 #pragma unroll
-      for (int it = 0; it < A_XPT; ++it) lds_dma16s(rx, base + (it * NW + wave) * 1024, xa_off[it], (uint32_t)step * 64u);
+      for (int it = 0; it < A_XPT; ++it)
+        if (!(a.debug & 8)) lds_dma16s(rx, base + (it * NW + wave) * 1024, xa_off[it], (uint32_t)step * 64u);
       if (wave < A_WPIECES) lds_dma16s(rw1, base + A_XB + wave * 1024, wa_off, (uint32_t)step * 64u);
     };
 
@@ -142,11 +152,27 @@ __global__ __launch_bounds__(512) void resunit_kernel(const ResUnitArgs ra) {
           xf[p] = *reinterpret_cast<const bf16x8*>(xb + (R < 384 ? R : 0) * 64 + ((g ^ ((R >> 2) & 3)) << 4));
         }
 #pragma unroll
-        for (int i = 0; i < MI1; ++i) {
+        for (int i = 0; i < MI1 && !(a.debug & 1); ++i) {
           acc1[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[0], acc1[0][i], 0, 0, 0);
           if (two) acc1[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[1], acc1[1][i], 0, 0, 0);
         }
       }
+    }
+    if constexpr (RES_FROM_LDS) {
+      // lane mapping of the (paired) epilogue: per half of the wave's 32 pixel rows, 8 rows x 8 chunks of 8 channels
+      // per store instruction; chunk c = channels [8c, 8c+8) = K step c/4 of phase A, 16-byte chunk c%4 of its row
+      static_assert(MI == 2 && TM == 32, "C = 64 layout");
+      const int crow = lane >> 3, cchunk = lane & 7;
+      int idx = 0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass, ++idx) {
+          const int q = wm * TM + h * 16 + pass * 8 + crow;
+          const int hr = (q / TW + 1) * HW2 + (q % TW) + 1;
+          rp.v[idx] = *reinterpret_cast<const bf16x8*>(s_ring + (cchunk >> 2) * A_STAGE + hr * 64 +
+                                                       (((cchunk & 3) ^ ((hr >> 2) & 3)) << 4));
+        }
     }
     __builtin_amdgcn_s_barrier();            // every wave is done with the phase-A stages: the ring may be reused
     // first W2 stage flies while `mid` is written (issued below, after the offsets are set up)
@@ -154,7 +180,7 @@ __global__ __launch_bounds__(512) void resunit_kernel(const ResUnitArgs ra) {
     // mid rows: lane = halo pixel, registers = mid channels (e&3) + 8*(e>>2) + 4*khalf
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      if (p == 1 && !two) break;
+      if ((p == 1 && !two) || (a.debug & 16)) break;
       const int hr = (wave + 8 * p) * 32 + r32;
       const int hy = hr / HW2, hx = hr - hy * HW2;
       const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
@@ -190,7 +216,14 @@ __global__ __launch_bounds__(512) void resunit_kernel(const ResUnitArgs ra) {
 #pragma unroll
     for (int it = 0; it < WIT; ++it) lds_dma16s(rw2, base + it * (NW * 1024), w_off[it], (uint32_t)((tap * CM + c * CK) * 2));
   };
-  issue_w(0, 0, 0);
+  if constexpr (ALLW) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) issue_w(c * 9 + tap, c, tap);
+  } else {
+    issue_w(0, 0, 0);
+  }
   __syncthreads();                        // `mid` (plain LDS stores of every wave) visible to all
 
   int hrow0[NI];
@@ -213,16 +246,20 @@ __global__ __launch_bounds__(512) void resunit_kernel(const ResUnitArgs ra) {
     const char* const hbuf = s_mid + c * HALO_B;
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
-      wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();       // W2 stage (c,tap) landed (and, first time, `mid` is complete)
-      if (tap < 8) {
-        issue_w(wb ^ 1, c, tap + 1);
-      } else if (c + 1 < NCH) {
-        issue_w(wb ^ 1, c + 1, 0);
+      if (!ALLW || (c == 0 && tap == 0)) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();     // W2 stage (c,tap) landed — with ALLW: every slice of every wave
+      }
+      if constexpr (!ALLW) {
+        if (tap < 8) {
+          issue_w(wb ^ 1, c, tap + 1);
+        } else if (c + 1 < NCH) {
+          issue_w(wb ^ 1, c + 1, 0);
+        }
       }
       const int dh = (tap * 11) >> 5, dw = tap - 3 * dh;
       const int toff = dh * HW2 + dw;
-      const char* const wbuf = s_ring + wb * WBUF_B;
+      const char* const wbuf = s_ring + (ALLW ? c * 9 + tap : wb) * WBUF_B;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int g = ks * 2 + khalf;
@@ -243,7 +280,7 @@ __global__ __launch_bounds__(512) void resunit_kernel(const ResUnitArgs ra) {
         for (int i = 0; i < MI; ++i)
 #pragma unroll
           for (int j = 0; j < NI; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+            if (!(a.debug & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
       }
       wb ^= 1;
     }
@@ -255,7 +292,18 @@ __global__ __launch_bounds__(512) void resunit_kernel(const ResUnitArgs ra) {
     return (yy < d.h && xx < d.w) ? ((long)(b * d.h + yy) * d.w + xx) : -1L;
   };
   __syncthreads();
-  epilogue_lds<MI, NI, TM>(a, acc, smem + wave * (TM * kEpiPitch), lane, wn * TN, pix_of);
+  if (a.debug & 4) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" ::"v"(acc[i][j]));
+#endif
+      }
+    return;
+  }
+  epilogue_lds<MI, NI, TM>(a, acc, smem + wave * (TM * kEpiPitch), lane, wn * TN, pix_of, RES_FROM_LDS ? &rp : nullptr);
 }
 
 template <int C>
@@ -309,7 +357,8 @@ extern "C" int yolo_resunit_fwd(const void* x, const void* w1_packed, const floa
   ra.c.steps = 0;
   ra.c.x_bytes = (uint32_t)x_bytes;
   ra.c.w_bytes = (uint32_t)w_bytes;
-  ra.c.debug = 0;
+  static const int dbg = getenv("YOLO_RESUNIT_DEBUG") ? atoi(getenv("YOLO_RESUNIT_DEBUG")) : 0;   // timing ablations only
+  ra.c.debug = dbg;
   ra.w1 = (const bf16_t*)w1_packed;
   ra.b1 = b1;
   ra.kpad1 = kpad1;
