@@ -18,7 +18,7 @@ using namespace yolo_conv;
 
 namespace {
 
-template <int TH, int TW, int BN, int WAVES_M, int WAVES_N, int CK, int HB>
+template <int TH, int TW, int BN, int WAVES_M, int WAVES_N, int CK, int HB, bool M16 = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv3x3_halo_kernel(const ConvArgs a) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = TH * TW;
@@ -105,13 +105,26 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv3x3_halo_kernel(co
     hrow0[j] = (q / TW) * HW2 + (q % TW);
   }
 
-  f32x16 acc[MI][NI];
+  static_assert(!M16 || (CK == 64 && TW == 16), "16x16x32 form: 64-channel chunks, 16-wide tiles");
+  constexpr int MI16 = M16 ? TN / 16 : 1, NI16 = M16 ? TM / 16 : 1;
+  f32x16 acc[M16 ? 1 : MI][M16 ? 1 : NI];
+  f32x4 acc16[MI16][NI16];
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+  for (int i = 0; i < (M16 ? 1 : MI); ++i)
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
+    for (int j = 0; j < (M16 ? 1 : NI); ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < MI16; ++i)
+#pragma unroll
+    for (int j = 0; j < NI16; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc16[i][j][e] = 0.f;
+  // 16x16x32 form: lane = (row c16 of a 16-block, 8-channel chunk q of a 32-channel K slice); a 16-pixel block is one
+  // row of the 16-wide tile
+  const int c16 = lane & 15, q16 = lane >> 4;
+  const int hrow16 = (wm * (TM / 16)) * HW2 + c16;
 
   const int n_chunks = d.cin / CK;
   issue_halo(0, 0, 0, HPT);
@@ -141,7 +154,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv3x3_halo_kernel(co
       const int dh = (tap * 11) >> 5, dw = tap - 3 * dh;
       const int toff = dh * HW2 + dw;
       const char* const wbuf = s_w + wb * WBUF_B;
-      if (!(a.debug & 4)) {
+      if constexpr (M16) {
+#pragma unroll
+        for (int kk = 0; kk < CK / 32; ++kk) {
+          const int g = kk * 4 + q16;
+          bf16x8 wf[MI16], xf[NI16];
+#pragma unroll
+          for (int i = 0; i < MI16; ++i) {
+            const int R = wn * TN + i * 16 + c16;
+            wf[i] = *reinterpret_cast<const bf16x8*>(wbuf + R * ROWB + ((g ^ ((R >> 1) & 7)) << 4));
+          }
+#pragma unroll
+          for (int j = 0; j < NI16; ++j) {
+            const int R = hrow16 + j * HW2 + toff;
+            xf[j] = *reinterpret_cast<const bf16x8*>(hbuf + R * ROWB + ((g ^ ((R >> 1) & 7)) << 4));
+          }
+#pragma unroll
+          for (int i = 0; i < MI16; ++i)
+#pragma unroll
+            for (int j = 0; j < NI16; ++j)
+              acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc16[i][j], 0, 0, 0);
+        }
+      } else if (!(a.debug & 4)) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const int g = ks * 2 + khalf;
@@ -185,7 +219,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv3x3_halo_kernel(co
     return;
   }
   __syncthreads();
-  epilogue_lds<MI, NI, TM>(a, acc, smem + wave * (TM * kEpiPitch), lane, n0 + wn * TN, pix_of);
+  if constexpr (M16) epilogue_lds16<MI, NI16, TM>(a, acc16, smem + wave * (TM * kEpiPitch), lane, n0 + wn * TN, pix_of);
+  else epilogue_lds<MI, NI, TM>(a, acc, smem + wave * (TM * kEpiPitch), lane, n0 + wn * TN, pix_of);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -307,13 +342,13 @@ __global__ __launch_bounds__(256) void conv1_nchw_kernel(const ConvArgs a, const
   }
 }
 
-template <int TH, int TW, int BN, int WAVES_M, int WAVES_N, int CK, int HB>
+template <int TH, int TW, int BN, int WAVES_M, int WAVES_N, int CK, int HB, bool M16 = false>
 int launch(const ConvArgs& a, hipStream_t s) {
   ConvArgs b = a;
   b.n_tiles = (a.d.cout + BN - 1) / BN;
   const long grid = (long)a.d.n * ((a.d.h + TH - 1) / TH) * ((a.d.w + TW - 1) / TW) * b.n_tiles;
   if (grid > 0x7fffffffL) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv grid too large");
-  hipLaunchKernelGGL((conv3x3_halo_kernel<TH, TW, BN, WAVES_M, WAVES_N, CK, HB>), dim3((unsigned)grid),
+  hipLaunchKernelGGL((conv3x3_halo_kernel<TH, TW, BN, WAVES_M, WAVES_N, CK, HB, M16>), dim3((unsigned)grid),
                      dim3(64 * WAVES_M * WAVES_N), 0, s, b);
   return yolo_check_launch("yolo_conv2d_fwd(halo)");
 }
@@ -335,6 +370,8 @@ int yolo_conv::launch_halo3x3(const ConvArgs& a, hipStream_t s) {
     // -12..-14 % per layer against 256 couts per block (146 KB, one block per CU); YOLO_CONV_DEBUG bit 1024 selects
     // the old form.  (128 couts with two halo buffers, 114 KB, is the worst of the three.)
     if (d.cout % 256 == 0 && (a.debug & 1024)) return one ? launch<16, 16, 256, 4, 2, 64, 1>(a, s) : launch<16, 16, 256, 4, 2, 64, 2>(a, s);
+    // v_mfma_f32_16x16x32_bf16 form (the chip holds a higher clock on it): -6 % per layer; bit 65536 selects 32x32x16
+    if (d.cout % 128 == 0 && !(a.debug & 65536)) return launch<16, 16, 128, 4, 2, 64, 1, true>(a, s);
     if (d.cout % 128 == 0) return launch<16, 16, 128, 4, 2, 64, 1>(a, s);
     return one ? launch<16, 16, 64, 4, 1, 64, 1>(a, s) : launch<16, 16, 64, 4, 1, 64, 2>(a, s);
   }
