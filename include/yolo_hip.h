@@ -81,6 +81,11 @@ YOLO_API int yolo_conv2d_fwd(const void* x, const void* w_packed, const float* b
  * w_packed / bias as for yolo_conv2d_fwd with d->cin = 8; 3x3, stride 1, cout 32, bf16 NHWC output. */
 YOLO_API int yolo_conv1_nchw_f32_fwd(const float* x_nchw, int cin_real, const void* w_packed, const float* bias,
                                      void* y, const YoloConvDesc* d, yolo_stream_t s);
+/* same, followed by MaxPool2d(2, 2) (the first ConvPoolBlock of YOLOv3-tiny, models/yolo_base.py:69-80 with
+ * yolov3_tiny.py:26): y_pooled is the bf16 NHWC view of the POOLED map [n, h/2, w/2, ...]; d still describes the
+ * conv (ho = h, wo = w).  cout 16 or 32. */
+YOLO_API int yolo_conv1_pool_nchw_f32_fwd(const float* x_nchw, int cin_real, const void* w_packed, const float* bias,
+                                          void* y_pooled, const YoloConvDesc* d, yolo_stream_t s);
 
 /* host-side helper (CPU): OIHW f32 [cout,cin_w,k,k] -> packed bf16 (round-to-nearest-even);
  * cin_w <= cin (extra input channels, e.g. the RGB->8 pad, get zero weights). */
@@ -174,7 +179,7 @@ YOLO_API int yolo_letterbox_u8_fwd(const uint8_t* src, int h, int w, int c, int 
 
 /* ---- batched launcher: run a recorded list of ops with one FFI crossing (host overhead only). */
 enum { YOLO_OP_CONV = 1, YOLO_OP_MAXPOOL = 2, YOLO_OP_SPP = 3, YOLO_OP_DWCONV = 4, YOLO_OP_CONV1_NCHW = 5,
-       YOLO_OP_RESUNIT = 6, YOLO_OP_STEM = 7, YOLO_OP_HEAD_DECODE = 8 };
+       YOLO_OP_RESUNIT = 6, YOLO_OP_STEM = 7, YOLO_OP_HEAD_DECODE = 8, YOLO_OP_CONV1_POOL = 9 };
 typedef struct YoloOp {
   int32_t kind, _pad;
   const void* x; const void* w; const float* bias; const void* residual; void* y; void* y_aux;

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("YOLO_HIP_LIB") or os.path.join(_HERE, "csrc", "libyol
 
 ACT_NONE, ACT_LEAKY01, ACT_RELU6 = 0, 1, 2
 DT_BF16, DT_F32 = 0, 1
-OP_CONV, OP_MAXPOOL, OP_SPP, OP_DWCONV, OP_CONV1_NCHW, OP_RESUNIT, OP_STEM, OP_HEAD_DECODE = 1, 2, 3, 4, 5, 6, 7, 8
+OP_CONV, OP_MAXPOOL, OP_SPP, OP_DWCONV, OP_CONV1_NCHW, OP_RESUNIT, OP_STEM, OP_HEAD_DECODE, OP_CONV1_POOL = 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 
 class YoloConvDesc(C.Structure):
@@ -43,6 +43,8 @@ SIGNATURES = {
     "yolo_conv2d_fwd": (C.c_int, [C.c_void_p] * 6 + [C.POINTER(YoloConvDesc), C.c_void_p]),
     "yolo_conv1_nchw_f32_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.POINTER(YoloConvDesc), C.c_void_p]),
+    "yolo_conv1_pool_nchw_f32_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.POINTER(YoloConvDesc), C.c_void_p]),
     "yolo_pack_conv_weight_f32": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
     "yolo_stem_supported": (C.c_int, [C.c_int] * 5),
     "yolo_stem_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

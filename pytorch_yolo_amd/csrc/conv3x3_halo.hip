@@ -232,11 +232,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv3x3_halo_kernel(co
 // (write 64 B per pixel); the implicit-GEMM kernel spent its time issuing nine 16-byte gathers per pixel.
 constexpr int kConv1TilesPerBlock = 5;
 
+// COUT = 32 or 16 output channels (rows COUT..31 of the MFMA tile carry zero weights); POOL fuses the MaxPool2d(2, 2)
+// that follows the first ConvBlock of YOLOv3-tiny (reference models/yolo_base.py:69-80, yolov3_tiny.py:26): the 16 x 16
+// tile is pooled out of the LDS staging and only the pooled map is written.
+template <int COUT, bool POOL>
 __global__ __launch_bounds__(256) void conv1_nchw_kernel(const ConvArgs a, const float* __restrict__ x_nchw, int cin_real) {
   constexpr int HW2 = 18, HP = 18 * 18, TM = 64;
-  constexpr int SP = 80;                                      // bf16 staging pitch: 32 couts (64 B) + 16 B pad
+  constexpr int SP = COUT * 2 + 16;                           // bf16 staging pitch: COUT couts + 16 B pad
+  constexpr int LPP = COUT / 8;                               // 16-byte lanes per pixel
   constexpr int HALO_B = ((HP * 16 + 1023) / 1024) * 1024;    // 6 KB
-  constexpr int LDS_B = 2 * HALO_B + 4 * TM * SP;             // 32.5 KB
+  constexpr int LDS_B = 2 * HALO_B + 4 * TM * SP;             // 32.5 KB (COUT 32)
   constexpr int TPB = kConv1TilesPerBlock;
   __shared__ __attribute__((aligned(16))) char smem[LDS_B];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -320,22 +325,47 @@ __global__ __launch_bounds__(256) void conv1_nchw_kernel(const ConvArgs a, const
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
+      for (int g4 = 0; g4 < COUT / 8; ++g4) {
         bf16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (bf16_t)apply_act(acc[j][g4 * 4 + e] + bias4[g4][e], d.act);
         *reinterpret_cast<bf16x4*>(stg + (j * 32 + r32) * SP + (g4 * 8 + khalf * 4) * 2) = o;
       }
     __builtin_amdgcn_wave_barrier();
-    bf16_t* const ybase = reinterpret_cast<bf16_t*>(a.y) + d.out_c_offset + (lane & 3) * 8;
+    if constexpr (POOL) {
+      // the wave's 64 pixels are 4 tile rows x 16 columns -> 2 x 8 pooled pixels; lane = (pooled pixel, 8-channel chunk)
+      const int pp = lane / LPP, chunk = lane % LPP;
+      const int hp = d.h >> 1, wp = d.w >> 1;                 // MaxPool2d(2, 2): floor
+      if (pp < 16) {
+        const int pr = pp >> 3, pc = pp & 7;
+        const int py = (y0 >> 1) + wave * 2 + pr, px = (x0 >> 1) + pc;
+        if (py < hp && px < wp) {
+          float m[8];
 #pragma unroll
-    for (int pass = 0; pass < TM / 16; ++pass) {
-      const int row = pass * 16 + (lane >> 2);
-      const int q = wave * TM + row;
-      const int yy = y0 + (q >> 4), xx = x0 + (q & 15);
-      if (yy < d.h && xx < d.w) {
-        const u32x4 val = *reinterpret_cast<const u32x4*>(stg + row * SP + (lane & 3) * 16);
-        *reinterpret_cast<u32x4*>(ybase + ((long)(b * d.h + yy) * d.w + xx) * d.out_c_total) = val;
+          for (int k = 0; k < 4; ++k) {
+            const int q = (2 * pr + (k >> 1)) * 16 + 2 * pc + (k & 1);
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + q * SP + chunk * 16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = k == 0 ? (float)v[e] : fmaxf(m[e], (float)v[e]);
+          }
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16_t)m[e];    // exact: the maximum is one of the bf16 inputs
+          *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(a.y) + ((long)(b * hp + py) * wp + px) * d.out_c_total +
+                                     d.out_c_offset + chunk * 8) = o;
+        }
+      }
+    } else {
+      bf16_t* const ybase = reinterpret_cast<bf16_t*>(a.y) + d.out_c_offset + (lane % LPP) * 8;
+#pragma unroll
+      for (int pass = 0; pass < TM / (64 / LPP); ++pass) {
+        const int row = pass * (64 / LPP) + lane / LPP;
+        const int q = wave * TM + row;
+        const int yy = y0 + (q >> 4), xx = x0 + (q & 15);
+        if (yy < d.h && xx < d.w) {
+          const u32x4 val = *reinterpret_cast<const u32x4*>(stg + row * SP + (lane % LPP) * 16);
+          *reinterpret_cast<u32x4*>(ybase + ((long)(b * d.h + yy) * d.w + xx) * d.out_c_total) = val;
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -382,14 +412,22 @@ int yolo_conv::launch_halo3x3(const ConvArgs& a, hipStream_t s) {
 
 
 // float32 NCHW input -> first conv layer (see conv1_nchw_kernel).  Returns 1 if the shape is not covered.
-int yolo_conv::launch_conv1_nchw(const ConvArgs& a, const float* x_nchw, int cin_real, hipStream_t s) {
+int yolo_conv::launch_conv1_nchw(const ConvArgs& a, const float* x_nchw, int cin_real, bool pool, hipStream_t s) {
   const YoloConvDesc& d = a.d;
-  if (d.ksize != 3 || d.stride != 1 || d.pad != 1 || d.cin != 8 || cin_real > 8 || d.cout != 32 || d.upsample2x ||
+  if (d.ksize != 3 || d.stride != 1 || d.pad != 1 || d.cin != 8 || cin_real > 8 || (d.cout != 32 && d.cout != 16) || d.upsample2x ||
       d.out_dtype != YOLO_DT_BF16 || d.kpad < 80 || a.res || a.aux)
     return 1;
+  if (pool && (d.h < 2 || d.w < 2)) return 1;
   const int tiles_x = (d.w + 15) / 16;
   const long grid = (long)d.n * ((d.h + 15) / 16) * ((tiles_x + kConv1TilesPerBlock - 1) / kConv1TilesPerBlock);
   if (grid > 0x7fffffffL) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv1 grid too large");
-  hipLaunchKernelGGL(conv1_nchw_kernel, dim3((unsigned)grid), dim3(256), 0, s, a, x_nchw, cin_real);
+  const dim3 g((unsigned)grid), blk(256);
+  if (d.cout == 32) {
+    if (pool) hipLaunchKernelGGL((conv1_nchw_kernel<32, true>), g, blk, 0, s, a, x_nchw, cin_real);
+    else hipLaunchKernelGGL((conv1_nchw_kernel<32, false>), g, blk, 0, s, a, x_nchw, cin_real);
+  } else {
+    if (pool) hipLaunchKernelGGL((conv1_nchw_kernel<16, true>), g, blk, 0, s, a, x_nchw, cin_real);
+    else hipLaunchKernelGGL((conv1_nchw_kernel<16, false>), g, blk, 0, s, a, x_nchw, cin_real);
+  }
   return yolo_check_launch("yolo_conv1_nchw_f32_fwd");
 }

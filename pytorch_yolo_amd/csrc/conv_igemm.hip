@@ -660,9 +660,10 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
 #undef YOLO_CFG
 }
 
-// First layer straight from the caller's float32 NCHW batch (fuses yolo_pack_input_nchw_f32 + conv).
-extern "C" int yolo_conv1_nchw_f32_fwd(const float* x_nchw, int cin_real, const void* w_packed, const float* bias, void* y,
-                                       const YoloConvDesc* dp, yolo_stream_t s) {
+// First layer straight from the caller's float32 NCHW batch (fuses yolo_pack_input_nchw_f32 + conv), optionally with
+// the MaxPool2d(2, 2) that follows it in YOLOv3-tiny.
+static int conv1_nchw(const float* x_nchw, int cin_real, const void* w_packed, const float* bias, void* y, const YoloConvDesc* dp,
+                      bool pool, yolo_stream_t s) {
   YOLO_REQUIRE(x_nchw && w_packed && bias && y && dp, "conv1: null pointer");
   const YoloConvDesc& d = *dp;
   YOLO_REQUIRE(cin_real >= 1 && cin_real <= 8 && d.cin == 8, "conv1: 1..8 input channels (packed K uses cin = 8)");
@@ -682,9 +683,19 @@ extern "C" int yolo_conv1_nchw_f32_fwd(const float* x_nchw, int cin_real, const 
   a.x_bytes = 0;
   a.w_bytes = 0;
   a.debug = 0;
-  const int rc = launch_conv1_nchw(a, x_nchw, cin_real, (hipStream_t)s);
-  if (rc == 1) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv1: shape not covered (3x3 s1, cout 32, bf16 out)");
+  const int rc = launch_conv1_nchw(a, x_nchw, cin_real, pool, (hipStream_t)s);
+  if (rc == 1) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv1: shape not covered (3x3 s1, cout 16 or 32, bf16 out)");
   return rc;
+}
+
+extern "C" int yolo_conv1_nchw_f32_fwd(const float* x_nchw, int cin_real, const void* w_packed, const float* bias, void* y,
+                                       const YoloConvDesc* dp, yolo_stream_t s) {
+  return conv1_nchw(x_nchw, cin_real, w_packed, bias, y, dp, false, s);
+}
+
+extern "C" int yolo_conv1_pool_nchw_f32_fwd(const float* x_nchw, int cin_real, const void* w_packed, const float* bias,
+                                            void* y_pooled, const YoloConvDesc* dp, yolo_stream_t s) {
+  return conv1_nchw(x_nchw, cin_real, w_packed, bias, y_pooled, dp, true, s);
 }
 
 extern "C" int yolo_conv2d_fwd(const void* x, const void* w_packed, const float* bias, const void* residual, void* y,

@@ -29,6 +29,9 @@ extern "C" int yolo_run_ops(const YoloOp* ops, int n_ops, yolo_stream_t s) {
       case YOLO_OP_CONV1_NCHW:
         rc = yolo_conv1_nchw_f32_fwd((const float*)o.x, d.res_c_total, o.w, o.bias, o.y, &d, s);
         break;
+      case YOLO_OP_CONV1_POOL:
+        rc = yolo_conv1_pool_nchw_f32_fwd((const float*)o.x, d.res_c_total, o.w, o.bias, o.y, &d, s);
+        break;
       case YOLO_OP_MAXPOOL:
         rc = yolo_maxpool_fwd(o.x, o.y, d.n, d.h, d.w, d.cin, d.in_c_total, d.in_c_offset, d.ho, d.wo, d.out_c_total,
                               d.out_c_offset, d.ksize, d.stride, d.pad, d.upsample2x /* dilation */, s);

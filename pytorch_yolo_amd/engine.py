@@ -28,7 +28,7 @@ import torch
 
 from . import kernels as K
 from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU6, DT_BF16, DT_F32, OP_CONV, OP_CONV1_NCHW, OP_DWCONV,
-                   OP_HEAD_DECODE, OP_MAXPOOL, OP_RESUNIT, OP_SPP, OP_STEM, YoloOp)
+                   OP_CONV1_POOL, OP_HEAD_DECODE, OP_MAXPOOL, OP_RESUNIT, OP_SPP, OP_STEM, YoloOp)
 
 # which residual-unit widths run as ONE launch (bit mask of C: 64 | 128 | 256); see DESIGN.md §3.1d for the
 # measurements behind the default.  YOLO_FUSE_RESUNIT overrides it (tuning only).
@@ -279,14 +279,32 @@ class Plan:
         nd = x.consumers[0]
         w, _ = nd.attrs["weight"]
         y = nd.outs[0]
-        ok = (w.shape[0] == 32 and w.shape[2] == 3 and nd.attrs["stride"] == 1 and not nd.attrs["has_res"]
+        ok = (w.shape[0] in (16, 32) and w.shape[2] == 3 and nd.attrs["stride"] == 1 and not nd.attrs["has_res"]
               and len(nd.outs) == 1 and "up_into" not in nd.attrs and not y.f32 and y.buf is not None
               and y.c_offset % 8 == 0)
         if ok and x.buf in self._bufs:
             self._bufs.remove(x.buf)          # no packed input buffer needed
         if ok:
             self._try_fuse_stem(nd)
+            if "fused_away" not in nd.attrs:
+                self._try_fuse_pool(nd)
         return ok
+
+    def _try_fuse_pool(self, nd1):
+        """First ConvPoolBlock of YOLOv3-tiny: conv1 followed only by MaxPool2d(2, 2) becomes ONE launch
+        (yolo_conv1_pool_nchw_f32_fwd); the full-resolution conv output is never written."""
+        if os.environ.get("YOLO_FUSE_POOL", "1") != "1":
+            return
+        mid = nd1.outs[0]
+        if len(mid.consumers) != 1 or mid.consumers[0].kind != "pool" or mid.c_offset != 0 or mid.buf.c_total != mid.c:
+            return
+        ndp = mid.consumers[0]
+        if (ndp.attrs["size"], ndp.attrs["stride"], ndp.attrs["pad"], ndp.attrs["dil"]) != (2, 2, 0, 1) or mid.h % 2 or mid.w % 2:
+            return
+        nd1.attrs["pool_into"] = ndp.outs[0]
+        ndp.attrs["fused_away"] = True
+        if mid.buf in self._bufs:
+            self._bufs.remove(mid.buf)
 
     def _try_fuse_stem(self, nd1):
         """Darknet stem: conv1 (3x3/s1 -> 32) followed only by a 3x3/s2 32 -> 64 conv becomes ONE launch
@@ -409,7 +427,11 @@ class Plan:
                                 aux=(aux.buf.c_total, aux.c_offset) if aux is not None else (0, 0))
                 op = YoloOp()
                 fused_first = self.fused_input and x is self.rec.input
-                op.kind = OP_CONV1_NCHW if fused_first else OP_CONV
+                pooled = nd.attrs.get("pool_into")
+                if pooled is not None:                     # conv1 + MaxPool2d(2, 2): the op writes the pooled map
+                    d.out_c_total, d.out_c_offset = pooled.buf.c_total, pooled.c_offset
+                    dst = pooled
+                op.kind = (OP_CONV1_POOL if pooled is not None else OP_CONV1_NCHW) if fused_first else OP_CONV
                 if fused_first:
                     d.res_c_total = self.rec.c_in          # real input channels (x pointer is patched per call)
                 op.x = None if fused_first else x.buf.tensor.data_ptr()
@@ -514,7 +536,7 @@ class Plan:
         for i in range(self.n_ops):
             op = self.op_array[i]
             d = op.conv
-            if op.kind in (OP_CONV, OP_CONV1_NCHW, OP_HEAD_DECODE):
+            if op.kind in (OP_CONV, OP_CONV1_NCHW, OP_CONV1_POOL, OP_HEAD_DECODE):
                 cin = self.rec.c_in if first else d.cin      # the first layer's 3 -> 8 channel pad is not work
                 first = False
                 total += 2.0 * d.n * d.ho * d.wo * d.cout * d.ksize * d.ksize * cin

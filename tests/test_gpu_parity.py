@@ -243,6 +243,33 @@ def test_fused_stem(n, cin, h, w):
     assert torch.all(y[..., :out_co] == -77.0) and torch.all(y[..., out_co + 64:] == -77.0)
 
 
+@pytest.mark.parametrize("cin,cout,h,w", [(3, 16, 64, 96), (3, 32, 32, 32), (1, 16, 38, 50)])
+def test_first_layer_fused_with_maxpool(cin, cout, h, w):
+    """yolo_conv1_pool_nchw_f32_fwd: first ConvBlock + MaxPool2d(2, 2) of YOLOv3-tiny in one launch (the planner picks it
+    for ConvPoolBlock): equals conv -> bf16 rounding -> pool of the two-launch path (max is exact on bf16 values)."""
+    from pytorch_yolo_amd import engine
+    from pytorch_yolo_amd._lib import OP_CONV1_POOL
+    from pytorch_yolo_amd.models.yolo_base import ConvPoolBlock
+    from pytorch_yolo_amd.utils.synthetic import synth_images, synth_state_dict
+    blk = ConvPoolBlock(cin, cout, pool_size=2, pool_stride=2).eval()
+    blk.load_state_dict(synth_state_dict(blk.state_dict(), 5))
+    x = synth_images(2, h, w, 7, channels=cin)
+    rec = engine.Recorder(2, cin, h, w)
+    blk._trace(rec, rec.input)
+    plan = engine.Plan(rec, torch.device(DEV), 0, max(h, w))
+    assert plan.fused_input and plan.op_array[0].kind == OP_CONV1_POOL and plan.n_ops == 1
+    got = blk(x.to(DEV)).cpu()
+    import os
+    os.environ["YOLO_FUSE_POOL"] = "0"
+    try:
+        blk2 = ConvPoolBlock(cin, cout, pool_size=2, pool_stride=2).eval()
+        blk2.load_state_dict(blk.state_dict())
+        want = blk2(x.to(DEV)).cpu()
+    finally:
+        del os.environ["YOLO_FUSE_POOL"]
+    assert got.shape == (2, cout, h // 2, w // 2) and torch.equal(got, want)
+
+
 @pytest.mark.parametrize("cin,h,w", [(3, 37, 50), (3, 64, 64), (1, 20, 33), (8, 16, 16)])
 def test_first_layer_fused_with_input_packing(cin, h, w):
     """yolo_conv1_nchw_f32_fwd: the first ConvBlock reads the float32 NCHW batch directly (no packed copy)."""
