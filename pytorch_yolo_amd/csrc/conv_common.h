@@ -49,6 +49,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 #endif
 }
 
+// LDS operations of this wave have completed (data in registers / visible in LDS); vector-memory traffic keeps flying
+__device__ __forceinline__ void wait_lds() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
+
 __device__ __forceinline__ void lds_dma16s(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, uint32_t voffset,
                                            uint32_t soffset) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16,

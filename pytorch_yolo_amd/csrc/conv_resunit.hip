@@ -306,6 +306,261 @@ __global__ __launch_bounds__(512) void resunit_kernel(const ResUnitArgs ra) {
   epilogue_lds<MI, NI, TM>(a, acc, smem + wave * (TM * kEpiPitch), lane, wn * TN, pix_of, RES_FROM_LDS ? &rp : nullptr);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// C = 64 (the unit on the 320 x 320 map): persistent, software-pipelined form.  The generic kernel above is a chain of
+// dependent waits per tile (x halo from HBM -> phase A -> W2 -> phase B -> epilogue) with only two blocks per CU to
+// hide them; ablation: 0.22 ms against an HBM floor of 0.095.  Here ONE block per CU walks its share of the tile list
+// with W1 / W2 / biases resident for the whole block (40 KB, loaded once) and the x halo of tile t+1 streaming into
+// LDS (LDS-DMA, one 128-byte row per halo pixel) while tile t runs phase B and its epilogue — no wait inside a tile
+// is longer than an LDS round trip.  The residual is taken from the x halo in LDS before it is overwritten.
+//   LDS: mid 21 KB | x halo 48 KB | W1 4 KB | W2 36 KB | per-wave fp32 store staging 34 KB   (144 KB)
+__global__ __launch_bounds__(512) void resunit64_kernel(const ResUnitArgs ra) {
+  constexpr int NW = 8, C = 64, CM = 32, TW = 16, HW2 = 18, HP = 18 * 18;
+  constexpr int TM = 32, MI = 2;                       // wave tile of phase B: 32 pixels x 64 couts
+  constexpr int MID_B = ((HP * 64 + 1023) / 1024) * 1024;            // 64-byte rows (32 mid channels), swizzle (R>>2)&3
+  constexpr int X_ROWS = 384, X_B = X_ROWS * 128;                    // 128-byte rows (64 x channels), swizzle (R>>1)&7
+  constexpr int W1_B = CM * 128;                                     // [32 mid couts][64 k]
+  constexpr int W2_B = 9 * C * 64;                                   // 9 taps x [64 couts][32 k]
+  constexpr int STG_B = NW * (TM / 2) * kEpiPitch2;
+  constexpr int LDS_B = MID_B + X_B + W1_B + W2_B + STG_B;
+  static_assert(LDS_B <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(16))) char smem[LDS_B];
+  char* const s_mid = smem;
+  char* const s_x = smem + MID_B;
+  char* const s_w1 = s_x + X_B;
+  char* const s_w2 = s_w1 + W1_B;
+  char* const s_stg = s_w2 + W2_B;
+
+  const ConvArgs& a = ra.c;
+  const YoloConvDesc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r32 = lane & 31, khalf = lane >> 5;
+
+  const int tiles_x = (d.w + 15) / 16, tiles_y = (d.h + 15) / 16;
+  const long total = (long)d.n * tiles_y * tiles_x;
+  const int lb = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int t_lo = (int)(lb * total / gridDim.x), t_hi = (int)((lb + 1) * total / gridDim.x);
+  if (t_lo >= t_hi) return;
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw1 = __builtin_amdgcn_make_buffer_rsrc((void*)ra.w1, 0, ra.w1_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+
+  // ---- LDS-DMA lane roles.  128-byte rows: 8 rows per 1-KiB piece, lane -> (row lane/8, slot lane%8), source chunk =
+  // slot ^ f(row) with f = (row >> 1) & 7.  x: 48 pieces = 6 per wave; W1: 4 pieces (waves 0..3).
+  const int frow8 = lane >> 3;
+  const int chunk8 = (lane & 7) ^ (((lane >> 4) + 4 * (wave & 1)) & 7);
+  int x_rel[6];          // element offset of this lane's source chunk relative to the tile's halo origin, or -1
+  int x_yx[6];
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {
+    const int hr = (it * NW + wave) * 8 + frow8;
+    const int hy = hr / HW2, hx = hr - hy * HW2;
+    x_rel[it] = hr < HP ? (hy * d.w + hx) * d.in_c_total + chunk8 * 8 : -1;
+    x_yx[it] = (hy << 8) | hx;
+  }
+  auto issue_x = [&](int b, int ty, int tx) {
+    const int y0 = ty * 16 - 1, x0 = tx * 16 - 1;                    // halo origin
+    const long base = ((long)(b * d.h + y0) * d.w + x0) * d.in_c_total + d.in_c_offset;
+    const bool interior = y0 >= 0 && y0 + HW2 <= d.h && x0 >= 0 && x0 + HW2 <= d.w;
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+      bool ok = x_rel[it] >= 0;
+      if (!interior) ok = ok && (unsigned)(y0 + (x_yx[it] >> 8)) < (unsigned)d.h && (unsigned)(x0 + (x_yx[it] & 255)) < (unsigned)d.w;
+      const uint32_t voff = ok ? (uint32_t)((base + x_rel[it]) * 2) : kOobOffset;
+      lds_dma16(rx, s_x + (it * NW + wave) * 1024, voff);
+    }
+  };
+  // one-time operands: W1 (32 rows x 128 B) and the nine W2 tap slices (64 rows x 64 B each: 16 rows per piece)
+  if (wave < 4) lds_dma16(rw1, s_w1 + wave * 1024, (uint32_t)((((wave * 8 + frow8) * ra.kpad1) + chunk8 * 8) * 2));
+  {
+    const int frow16 = lane >> 2, chunk4 = (lane & 3) ^ ((lane >> 4) & 3);
+    // 36 pieces (tap-major: 4 pieces per tap): wave w takes pieces w, w+8, ... (< 36)
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+      const int piece = it * NW + wave;
+      if (piece < 36) {
+        const int tap = piece >> 2, row = (piece & 3) * 16 + frow16;
+        lds_dma16(rw2, s_w2 + piece * 1024, (uint32_t)(((row * d.kpad) + tap * CM + chunk4 * 8) * 2));
+      }
+    }
+  }
+
+  // ---- per-lane constants
+  f32x16 bias1;                                          // mid channel (e&3) + 8*(e>>2) + 4*khalf
+  f32x16 bias2[MI];
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      bias1[g4 * 4 + e] = ra.b1[g4 * 8 + khalf * 4 + e];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) bias2[i][g4 * 4 + e] = a.bias[i * 32 + g4 * 8 + khalf * 4 + e];
+    }
+  // phase A: halo pixel blocks {wave, wave + 8} of the 11 (x 32 rows); row offsets are tile-invariant
+  const bool two = wave + 8 < 11;
+  int a_rd[2], a_wr[2], a_pos[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int hr = (wave + 8 * p) * 32 + r32;
+    const int hy = hr / HW2, hx = hr - hy * HW2;
+    a_rd[p] = hr < X_ROWS ? hr * 128 : 0;
+    a_wr[p] = hr < HP ? ((hr * 64 + khalf * 8) ^ (((hr >> 2) & 3) << 4)) : -1;
+    a_pos[p] = (hy << 8) | hx;
+  }
+  const int a_sw[2] = {(((wave) * 32 + r32) >> 1) & 7, (((wave + 8) * 32 + r32) >> 1) & 7};
+  // phase B: output pixel q = wave*32 + r32 -> halo row of tap (0,0)
+  const int hrow0 = ((wave * 32 + r32) >> 4) * HW2 + (r32 & 15);
+  // residual chunks (epilogue lane mapping: 8 rows x 8 chunks per pass, two halves x two passes)
+  int res_off[4];
+  {
+    const int crow = lane >> 3, cchunk = lane & 7;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int q = wave * TM + (k >> 1) * 16 + (k & 1) * 8 + crow;
+      const int hr = (q / TW + 1) * HW2 + (q % TW) + 1;
+      res_off[k] = hr * 128 + ((cchunk ^ ((hr >> 1) & 7)) << 4);
+    }
+  }
+  char* const stg = s_stg + wave * ((TM / 2) * kEpiPitch2);
+
+  int tx = t_lo % tiles_x, ty = (t_lo / tiles_x) % tiles_y, b = t_lo / (tiles_x * tiles_y);
+  int ntx = tx, nty = ty, nb = b;
+  auto advance = [&](int& x_, int& y_, int& b_) {
+    if (++x_ == tiles_x) {
+      x_ = 0;
+      if (++y_ == tiles_y) {
+        y_ = 0;
+        ++b_;
+      }
+    }
+  };
+  issue_x(b, ty, tx);
+  bool prev_full = false;                 // first tile: wait for everything (W1 / W2 / halo)
+
+  for (int t = t_lo; t < t_hi; ++t, advance(tx, ty, b)) {
+    const int x0 = tx * 16, y0 = ty * 16;
+    // the halo of tile t must have landed; the previous tile's stores, issued after it, may still be in flight:
+    // a full tile issues exactly 4 (8 with the pre-add copy) store instructions per wave after its halo prefetch
+    if (prev_full && a.aux) wait_vmcnt<8>();
+    else if (prev_full) wait_vmcnt<4>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();         // x halo of tile t (and, first time, W1 / W2) landed; mid / s_x free of readers
+
+    // ================= phase A: mid = act(W1 . x_halo + b1), K = 64 in one LDS-resident stage =================
+    f32x16 acc1[2] = {bias1, bias1};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int g = ks * 2 + khalf;
+      const bf16x8 wf = *reinterpret_cast<const bf16x8*>(s_w1 + r32 * 128 + ((g ^ ((r32 >> 1) & 7)) << 4));
+      const bf16x8 xf0 = *reinterpret_cast<const bf16x8*>(s_x + a_rd[0] + ((g ^ a_sw[0]) << 4));
+      acc1[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf0, acc1[0], 0, 0, 0);
+      if (two) {
+        const bf16x8 xf1 = *reinterpret_cast<const bf16x8*>(s_x + a_rd[1] + ((g ^ a_sw[1]) << 4));
+        acc1[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf1, acc1[1], 0, 0, 0);
+      }
+    }
+    bf16x8 res[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) res[k] = *reinterpret_cast<const bf16x8*>(s_x + res_off[k]);
+    wait_lds();
+    __builtin_amdgcn_s_barrier();         // every wave has what it needs from s_x (its LDS reads have completed)
+    if (t + 1 < t_hi) {                   // the next tile's halo streams in under phase B and the epilogue
+      advance(ntx, nty, nb);
+      issue_x(nb, nty, ntx);
+    }
+    const bool interior = y0 >= 1 && y0 + 17 <= d.h && x0 >= 1 && x0 + 17 <= d.w;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      if ((p == 1 && !two) || a_wr[p] < 0) continue;
+      bool inside = true;
+      if (!interior) {
+        const int yy = y0 - 1 + (a_pos[p] >> 8), xx = x0 - 1 + (a_pos[p] & 255);
+        inside = (unsigned)yy < (unsigned)d.h && (unsigned)xx < (unsigned)d.w;
+      }
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)apply_act(acc1[p][g4 * 4 + e], d.act);
+        u32x2 bits = __builtin_bit_cast(u32x2, o);
+        if (!inside) bits = u32x2{0u, 0u};
+        *reinterpret_cast<u32x2*>(s_mid + (a_wr[p] ^ (g4 << 4))) = bits;
+      }
+    }
+    wait_lds();
+    __builtin_amdgcn_s_barrier();         // mid complete
+
+    // ================= phase B: 3x3 over mid, W2 resident =================
+    f32x16 acc[MI] = {bias2[0], bias2[1]};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dh = tap / 3, dw = tap - 3 * dh;
+      const int R = hrow0 + dh * HW2 + dw;
+      const char* const xrow = s_mid + R * 64;
+      const int swx = (R >> 2) & 3;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int g = ks * 2 + khalf;
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xrow + ((g ^ swx) << 4));
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int Rw = i * 32 + r32;
+          const bf16x8 wf = *reinterpret_cast<const bf16x8*>(s_w2 + tap * 4096 + Rw * 64 + ((g ^ ((Rw >> 2) & 3)) << 4));
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[i], 0, 0, 0);
+        }
+      }
+    }
+
+    // ================= epilogue: act, (+ pre-add copy), + x, 128-byte lines =================
+    {
+      const int crow = lane >> 3, cchunk = lane & 7;
+      const bool full = y0 + 16 <= d.h && x0 + 16 <= d.w;
+      prev_full = full;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if ((r32 >> 4) == h) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              f32x4 v;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[i][g4 * 4 + e], d.act);
+              *reinterpret_cast<f32x4*>(stg + (r32 & 15) * kEpiPitch2 + i * 128 + (g4 * 8 + khalf * 4) * 4) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+          const int lrow = pass * 8 + crow;
+          const int q = wave * TM + h * 16 + lrow;
+          const int yy = y0 + (q >> 4), xx = x0 + (q & 15);
+          if (full || (yy < d.h && xx < d.w)) {
+            const long pix = (long)(b * d.h + yy) * d.w + xx;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + lrow * kEpiPitch2 + cchunk * 32);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + lrow * kEpiPitch2 + cchunk * 32 + 16);
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            if (a.aux) {
+              bf16x8 o;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+              *reinterpret_cast<bf16x8*>(a.aux + pix * d.aux_c_total + d.aux_c_offset + cchunk * 8) = o;
+            }
+            const bf16x8 rv = res[h * 2 + pass];
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(v[e] + (float)rv[e]);
+            *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(a.y) + pix * d.out_c_total + d.out_c_offset + cchunk * 8) = o;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+}
+
 template <int C>
 int launch(const ResUnitArgs& ra, hipStream_t s) {
   const YoloConvDesc& d = ra.c.d;
@@ -363,6 +618,18 @@ extern "C" int yolo_resunit_fwd(const void* x, const void* w1_packed, const floa
   ra.b1 = b1;
   ra.kpad1 = kpad1;
   ra.w1_bytes = (uint32_t)w1_bytes;
+  if (C == 64 && !(ra.c.debug & 32)) {        // persistent, software-pipelined form (YOLO_RESUNIT_DEBUG bit 32: generic kernel)
+    static const int n_cu = [] {
+      int dev = 0, v = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+        v = 256;
+      return v;
+    }();
+    const long tiles = (long)d.n * ((d.h + 15) / 16) * ((d.w + 15) / 16);
+    const long grid = tiles < n_cu ? tiles : n_cu;
+    hipLaunchKernelGGL(resunit64_kernel, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)s, ra);
+    return yolo_check_launch("yolo_resunit_fwd");
+  }
   if (C == 64) return launch<64>(ra, (hipStream_t)s);
   if (C == 128) return launch<128>(ra, (hipStream_t)s);
   return launch<256>(ra, (hipStream_t)s);
