@@ -298,7 +298,8 @@ __global__ __launch_bounds__(256) void conv1_nchw_kernel(const ConvArgs a, const
   fetch(0);
   for (int t = 0; t < n_t; ++t) {
     commit(t & 1);
-    __syncthreads();                       // halo t visible; (also: everyone is past the reads of halo t-2's buffer)
+    wait_lds();                            // LDS-only barrier: the previous tile's stores stay in flight
+    __builtin_amdgcn_s_barrier();          // halo t visible; (also: everyone is past the reads of halo t-2's buffer)
     if (t + 1 < n_t) fetch(t + 1);         // global loads fly during the MFMAs and the stores below
     const char* const hbuf = smem + (t & 1) * HALO_B;
     const int x0 = (tx0 + t) * 16;

@@ -188,7 +188,9 @@ __global__ __launch_bounds__(512) void stem_kernel(const StemArgs a) {
   for (int t = t_lo; t < t_hi; ++t, advance(tx, ty, b)) {
     const int ox0 = tx * 16, oy0 = ty * 16;
     commit();
-    __syncthreads();                       // input halo t (and, first time, W2) in LDS; every wave has left phase B of t-1
+    wait_lds();                            // (an LDS-only barrier: __syncthreads() would also drain the previous tile's
+    __builtin_amdgcn_s_barrier();          //  stores and, below, the prefetch loads it is supposed to overlap)
+                                           // input halo t (and, first time, W2) in LDS; every wave has left phase B of t-1
     if (t + 1 < t_hi) {                    // global loads fly during both MFMA phases
       advance(ntx, nty, nb);
       fetch(nb, nty, ntx);
@@ -223,7 +225,8 @@ __global__ __launch_bounds__(512) void stem_kernel(const StemArgs a) {
         }
       }
     }
-    __syncthreads();                       // mid complete
+    wait_lds();
+    __builtin_amdgcn_s_barrier();          // mid complete
 
     // ================= phase B: y = act(conv3x3/s2(mid) + b2), 32 pixels x 64 couts per wave =================
     f32x16 acc2[2] = {bias2[0], bias2[1]};
