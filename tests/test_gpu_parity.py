@@ -119,6 +119,43 @@ def test_conv_kernel(case):
         assert torch.all(aux[..., :8] == -77.0)
 
 
+BIG_CONV_CASES = [
+    # shapes of the SPP-640 layer list at 16 images: each one selects a different tile configuration in yolo_conv2d_launch
+    (16, 20, 20, 1024, 512, 1, True),     # 8-wave 128x128 tiles, three-stage ring (1x1 on the 20x20 maps)
+    (16, 40, 40, 512, 256, 1, False),     # 16-wave 128x256 tiles, three stages (1x1 on the 40x40 maps)
+    (16, 20, 20, 256, 512, 3, True),      # 128x256 tiles, 8 MFMA waves + 4 loader waves, three stages
+    (8, 40, 40, 128, 512, 3, True),       # 16-wave 256x256 tiles
+    (4, 80, 80, 256, 128, 1, False),      # 256x128 tiles, 32-deep stages (short-K 1x1 on the 80x80 maps)
+    (2, 160, 160, 64, 128, 3, True),      # halo kernel, one 64-channel chunk, 16x16x32 MFMA, two blocks per CU
+    (2, 161, 160, 32, 128, 3, False),     # 8-wave 128x128 tiles through the gather path (map does not tile by 16 well enough)
+]
+
+
+@pytest.mark.parametrize("case", BIG_CONV_CASES, ids=lambda c: "n%d_%dx%d_c%d-%d_k%d_r%d" % tuple(int(v) for v in c))
+def test_conv_tile_configurations(case):
+    """The tile rules of yolo_conv2d_launch are exercised at the sizes that trigger them (the small CONV_CASES all land
+    in two or three configurations): every configuration against fp32 torch on the same bf16-rounded operands."""
+    from pytorch_yolo_amd import kernels as K
+    from pytorch_yolo_amd._lib import ACT_LEAKY01
+    n, h, w, cin, cout, k, use_res = case
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(n, cout, h, w, generator=g) if use_res else None
+    xin, rin = _nhwc(x), (_nhwc(res) if use_res else None)
+    y = torch.empty(n, h, w, cout, dtype=torch.bfloat16, device=DEV)
+    wp, bp, kpad, cout_pad = K.pack_conv_weight(wt, bias, cin)
+    d = K.conv_desc(n=n, h=h, w=w, cin=cin, in_c_total=cin, in_c_offset=0, cout=cout, out_c_total=cout, out_c_offset=0,
+                    ksize=k, stride=1, act=ACT_LEAKY01, kpad=kpad, cout_pad=cout_pad, res=(cout, 0) if use_res else (0, 0))
+    K.conv2d(xin, wp.to(DEV), bp.to(DEV), y, d, residual=rin)
+    torch.cuda.synchronize()
+    ref = F.leaky_relu(F.conv2d(_bf16r(x), _bf16r(wt), bias, padding=(k - 1) // 2), 0.1)
+    if use_res:
+        ref = ref + _bf16r(res)
+    torch.testing.assert_close(_nchw(y), ref, rtol=1e-2, atol=2e-2)
+
+
 @pytest.mark.parametrize("n,h,w,c,use_aux", [(1, 80, 80, 256, False), (2, 96, 80, 128, True), (1, 94, 100, 64, False),
                                               (2, 80, 112, 256, True)])
 def test_fused_residual_unit(n, h, w, c, use_aux):
@@ -171,7 +208,7 @@ def test_fused_residual_unit(n, h, w, c, use_aux):
 
 @pytest.mark.parametrize("n,h,w,cin,k,nc,act", [(2, 20, 20, 256, 1, 80, "leaky"), (3, 13, 13, 512, 1, 80, "none"),
                                                   (1, 10, 12, 64, 3, 80, "leaky"), (2, 8, 8, 72, 1, 3, "none"),
-                                                  (1, 26, 26, 128, 1, 20, "none")])
+                                                  (1, 26, 26, 128, 1, 20, "none"), (2, 14, 14, 96, 1, 80, "leaky")])
 def test_fused_head_decode(n, h, w, cin, k, nc, act):
     """yolo_head_decode_fwd (head conv with the YOLOLayer decode as its epilogue) against the two-launch path
     (yolo_conv2d_fwd to an fp32 NHWC head + yolo_decode_fwd): p and io agree to fp32 summation-order noise, image
