@@ -417,6 +417,33 @@ def test_nms_vs_oracle_and_golden(name):
         np.testing.assert_allclose(dets[b][:, :4], g[f"dets_{b}"][:, :4], rtol=2e-6, atol=2e-4)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_nms_random_sweep_vs_oracle(seed):
+    """Random batch sizes, row counts, class counts (incl. 1, 2, 3, 5, 7: the class scan splits them over four lanes
+    unevenly) and thresholds: kept indices and all seven columns bit-equal to the oracle; ties in the class maximum are
+    forced on some rows (first maximum must win, torch.max semantics of utils.py:212)."""
+    from oracle import nms as onms
+    rng = np.random.default_rng(1000 + seed)
+    bs = int(rng.integers(1, 4))
+    rows = int(rng.choice([17, 64, 65, 300, 1000]))
+    nc = int(rng.choice([1, 2, 3, 5, 7, 20, 80]))
+    conf, iou = float(rng.choice([0.05, 0.1, 0.3])), float(rng.choice([0.3, 0.5, 0.7]))
+    pred = C.synth_predictions(2000 + seed, bs, rows, nc)
+    if nc > 1:                                   # exact ties between two classes on a tenth of the rows
+        tie = rng.random((bs, rows)) < 0.1
+        a, b2 = rng.integers(0, nc, 2)
+        top = pred[..., 5:].max(-1)
+        for cls in (int(a), int(b2)):
+            pred[..., 5 + cls] = np.where(tie, top, pred[..., 5 + cls])
+    dets, idx, _ = _run_nms(pred, conf, iou)
+    odets, okept = onms.non_max_suppression(pred.copy(), conf, iou)
+    for b in range(bs):
+        if odets[b] is None:
+            assert dets[b] is None
+            continue
+        assert np.array_equal(idx[b], okept[b]) and np.array_equal(dets[b], odets[b])
+
+
 def test_nms_kat_and_non_mutating_default():
     kat = (C.NMS_KAT_ARGS['conf_thres'], C.NMS_KAT_ARGS['nms_thres'])
     dets, idx, after = _run_nms(C.NMS_KAT_ROWS[None], *kat)
