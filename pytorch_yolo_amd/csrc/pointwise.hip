@@ -67,29 +67,36 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const bf16_t* __restrict__
 // SPP pyramid: one block = one image x 8 channels; the hxw plane lives in LDS; separable running max
 // (rows then columns) gives 5/9/13 windows in one pass.  Reads slice [3c,4c) of the concat buffer,
 // writes slices [0,c) [c,2c) [2c,3c).
+// bf16 pairs as order-preserving int16 pairs (x ^ 0x7fff for negative halves; an involution): the 5/9/13 window maxima
+// then cost ONE v_pk_max_i16 per 32-bit word and tap instead of unpack + two fmax
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ u32x4 bf16_sortable(u32x4 v) {
+  return v ^ (((v >> 15) & 0x00010001u) * 0x7fffu);
+}
+__device__ __forceinline__ u32x4 pk_max(u32x4 a, u32x4 b) {
+  return __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b)));
+}
+
 __global__ __launch_bounds__(256) void spp_kernel(bf16_t* __restrict__ buf, int h, int w, int c) {
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-  u32x4* plane = reinterpret_cast<u32x4*>(lds_raw);  // [h*w] input, then 3 x [h*w] row-maxima
+  u32x4* plane = reinterpret_cast<u32x4*>(lds_raw);  // [h*w] input, then 3 x [h*w] row-maxima (all in sortable form)
   const int hw = h * w, ct = 4 * c;
   const int cg = c / 8;
   const long b = blockIdx.x / cg;
   const int g = blockIdx.x % cg;
   bf16_t* base = buf + b * hw * ct + g * 8;
-  for (int p = threadIdx.x; p < hw; p += 256) plane[p] = *reinterpret_cast<const u32x4*>(base + (long)p * ct + 3 * c);
+  for (int p = threadIdx.x; p < hw; p += 256) plane[p] = bf16_sortable(*reinterpret_cast<const u32x4*>(base + (long)p * ct + 3 * c));
   __syncthreads();
   for (int p = threadIdx.x; p < hw; p += 256) {
     const int yy = p / w, xx = p - yy * w;
-    float m[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
-    max8(m, plane[p]);
+    u32x4 m = plane[p];
     for (int r = 1; r <= 6; ++r) {
-      if (xx - r >= 0) max8(m, plane[p - r]);
-      if (xx + r < w) max8(m, plane[p + r]);
-      if (r == 2) plane[hw + p] = pack8(m);
-      if (r == 4) plane[2 * hw + p] = pack8(m);
+      if (xx - r >= 0) m = pk_max(m, plane[p - r]);
+      if (xx + r < w) m = pk_max(m, plane[p + r]);
+      if (r == 2) plane[hw + p] = m;
+      if (r == 4) plane[2 * hw + p] = m;
     }
-    plane[3 * hw + p] = pack8(m);
+    plane[3 * hw + p] = m;
   }
   __syncthreads();
   for (int p = threadIdx.x; p < hw; p += 256) {
@@ -98,12 +105,12 @@ __global__ __launch_bounds__(256) void spp_kernel(bf16_t* __restrict__ buf, int 
     for (int lvl = 0; lvl < 3; ++lvl) {
       const int rad = 2 + 2 * lvl;
       const u32x4* rows = plane + (lvl + 1) * hw;
-      float m[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
-      for (int r = -rad; r <= rad; ++r)
-        if ((unsigned)(yy + r) < (unsigned)h) max8(m, rows[p + r * w]);
-      *reinterpret_cast<u32x4*>(base + (long)p * ct + lvl * c) = pack8(m);
+      u32x4 m = rows[p];
+      for (int r = 1; r <= rad; ++r) {
+        if (yy - r >= 0) m = pk_max(m, rows[p - r * w]);
+        if (yy + r < h) m = pk_max(m, rows[p + r * w]);
+      }
+      *reinterpret_cast<u32x4*>(base + (long)p * ct + lvl * c) = bf16_sortable(m);
     }
   }
 }
