@@ -104,16 +104,27 @@ __global__ __launch_bounds__(256) void nms_filter_kernel(float* __restrict__ pre
     have = lh || rh;
     all_finite = all_finite && of;
   }
-  if (!live || seg != 0) return;
-  const float conf = row[4] * best;                                              // utils.py:213
-  if (mutate) src[rloc * no + 4] = conf;
-  const float bw = row[2], bh = row[3];
-  all_finite = all_finite && finite_f(row[0]) && finite_f(row[1]) && finite_f(bw) && finite_f(bh) && finite_f(conf);
-  const bool keep = (conf > conf_thres) && (bw > min_wh) && (bh > min_wh) && all_finite;  // :216-218
-  if (keep) {
-    const int pos = atomicAdd(&counts[b], 1);
-    keys[(long)b * key_pitch + pos] = make_key(arg, conf, r0 + rloc);
+  // survivors are appended with ONE global atomic per block: thousands of same-address atomics per image (one per
+  // surviving row) serialise in L2 and were most of this kernel's time.  The slot order inside an image is free —
+  // nms_merge sorts the keys, and a key carries its row.
+  __shared__ int s_cnt, s_base;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  bool keep = false;
+  float conf = 0.f;
+  int pos = 0;
+  if (live && seg == 0) {
+    conf = row[4] * best;                                                        // utils.py:213
+    if (mutate) src[rloc * no + 4] = conf;
+    const float bw = row[2], bh = row[3];
+    all_finite = all_finite && finite_f(row[0]) && finite_f(row[1]) && finite_f(bw) && finite_f(bh) && finite_f(conf);
+    keep = (conf > conf_thres) && (bw > min_wh) && (bh > min_wh) && all_finite;  // :216-218
+    if (keep) pos = atomicAdd(&s_cnt, 1);                                        // LDS atomic
   }
+  __syncthreads();
+  if (threadIdx.x == 0 && s_cnt > 0) s_base = atomicAdd(&counts[b], s_cnt);
+  __syncthreads();
+  if (keep) keys[(long)b * key_pitch + s_base + pos] = make_key(arg, conf, r0 + rloc);
 }
 
 // ---------------------------------------------------------------------------------------------------
