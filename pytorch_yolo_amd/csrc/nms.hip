@@ -46,6 +46,10 @@ __device__ __forceinline__ int key_row(u64 k) { return (int)(k & 0xfffffu); }
 
 __device__ __forceinline__ bool finite_f(float v) { return (__float_as_uint(v) & 0x7f800000u) != 0x7f800000u; }
 
+__device__ __forceinline__ float readlane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void nms_filter_kernel(float* __restrict__ pred, int rows, int no, float conf_thres,
                                                          float min_wh, int mutate, u64* __restrict__ keys,
@@ -128,11 +132,19 @@ __global__ __launch_bounds__(256) void nms_filter_kernel(float* __restrict__ pre
 }
 
 // ---------------------------------------------------------------------------------------------------
-__device__ void block_bitonic_sort(u64* keys, int n_pad) {
+// Bitonic sort of n_pad (power of two) keys by the whole block.  Thread t owns pair slots t, t + 1024, ...; a wave's 64
+// consecutive slots touch one private 128-key chunk in every stage whose stride is <= 64, so in LDS those stages need
+// no block barrier (a wave's LDS instructions execute in order): of the 78 stages of a 4096-key sort only 15 keep
+// their __syncthreads().  `wave_local_ok` is false for keys in global memory (no such ordering there).
+__device__ void block_bitonic_sort(u64* keys, int n_pad, bool wave_local_ok) {
+  const int pairs = n_pad >> 1;
+  bool prev_local = false;
   for (int k = 2; k <= n_pad; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = threadIdx.x; t < (n_pad >> 1); t += kMergeThreads) {
-        const int i = ((t / j) * (j << 1)) + (t % j);
+    for (int j = k >> 1, lj = 31 - __builtin_clz(j); j > 0; j >>= 1, --lj) {
+      const bool local = wave_local_ok && j <= 64;
+      if (!local && prev_local) __syncthreads();          // the other waves' private stages must be complete
+      for (int t = threadIdx.x; t < pairs; t += kMergeThreads) {
+        const int i = ((t >> lj) << (lj + 1)) + (t & (j - 1));
         const int l = i + j;
         const bool up = (i & k) == 0;
         const u64 a = keys[i], c = keys[l];
@@ -141,8 +153,84 @@ __device__ void block_bitonic_sort(u64* keys, int n_pad) {
           keys[l] = a;
         }
       }
-      __syncthreads();
+      if (local) {
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      } else {
+        __syncthreads();
+      }
+      prev_local = local;
     }
+  }
+  if (prev_local) __syncthreads();
+}
+
+// Sort of 1024 * KPT keys held in LDS, with the keys in REGISTERS (thread t owns keys [t*KPT, (t+1)*KPT)): bitonic
+// strides below KPT are compare-exchanges inside a thread, strides below 64*KPT are wave shuffles, and only the
+// remaining ones (10 of the 78 stages of a 4096-key sort) go through LDS with block barriers.  The LDS round trips of
+// the plain network were 54 % of nms_merge (s_memtime stamps: 146 k of 268 k cycles per image).
+template <int KPT>
+__device__ __forceinline__ void cmpx(u64 (&r)[KPT], int lo, int hi, bool up) {
+  const u64 a = r[lo], c = r[hi];
+  const bool sw = (a > c) == up;
+  r[lo] = sw ? c : a;
+  r[hi] = sw ? a : c;
+}
+template <int KPT>
+__device__ void block_sort_regs(u64* keys) {
+  constexpr int N = kMergeThreads * KPT;
+  const int tid = threadIdx.x;
+  u64 r[KPT];
+#pragma unroll
+  for (int e = 0; e < KPT; ++e) r[e] = keys[tid * KPT + e];
+  for (int k = 2; k <= N; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j < KPT) {                                   // partner key lives in this thread
+#pragma unroll
+        for (int jj = KPT >> 1; jj > 0; jj >>= 1) {
+          if (jj != j) continue;
+#pragma unroll
+          for (int e = 0; e < KPT; ++e)
+            if ((e & jj) == 0) cmpx<KPT>(r, e, e | jj, ((tid * KPT + e) & k) == 0);
+        }
+      } else if (j < 64 * KPT) {                       // partner key lives in another lane of this wave
+        const int lx = j / KPT;
+#pragma unroll
+        for (int e = 0; e < KPT; ++e) {
+          const int i = tid * KPT + e;
+          const u64 o = __shfl_xor(r[e], lx);
+          const bool take_min = ((i & j) == 0) == ((i & k) == 0);
+          r[e] = take_min ? (o < r[e] ? o : r[e]) : (o > r[e] ? o : r[e]);
+        }
+      } else {                                         // partner key lives in another wave: through LDS
+#pragma unroll
+        for (int e = 0; e < KPT; ++e) keys[tid * KPT + e] = r[e];
+        __syncthreads();
+        u64 o[KPT];
+#pragma unroll
+        for (int e = 0; e < KPT; ++e) o[e] = keys[(tid * KPT + e) ^ j];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < KPT; ++e) {
+          const int i = tid * KPT + e;
+          const bool take_min = ((i & j) == 0) == ((i & k) == 0);
+          r[e] = take_min ? (o[e] < r[e] ? o[e] : r[e]) : (o[e] > r[e] ? o[e] : r[e]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < KPT; ++e) keys[tid * KPT + e] = r[e];
+  __syncthreads();
+}
+// n_pad: power of two, kMergeThreads <= n_pad <= kLdsKeys, keys in LDS
+__device__ void block_sort_lds(u64* keys, int n_pad) {
+  switch (n_pad / kMergeThreads) {
+    case 1: block_sort_regs<1>(keys); break;
+    case 2: block_sort_regs<2>(keys); break;
+    case 4: block_sort_regs<4>(keys); break;
+    default: block_sort_regs<8>(keys); break;
   }
 }
 
@@ -173,7 +261,7 @@ __global__ __launch_bounds__(kMergeThreads) void nms_merge_kernel(const MergeArg
     if (tid == 0) a.out_count[b] = 0;
     return;
   }
-  int n_pad = 1;
+  int n_pad = kMergeThreads;                        // the register sort handles 1024 * {1, 2, 4, 8} keys
   while (n_pad < n) n_pad <<= 1;
   u64* gkeys = a.keys + (long)b * a.key_pitch;
   u64* keys;
@@ -187,7 +275,8 @@ __global__ __launch_bounds__(kMergeThreads) void nms_merge_kernel(const MergeArg
   for (int c = tid; c < a.nc; c += kMergeThreads) s_seg_len[c] = 0;
   if (tid == 0) s_nout = 0;
   __syncthreads();
-  block_bitonic_sort(keys, n_pad);
+  if (keys == s_keys) block_sort_lds(keys, n_pad);
+  else block_bitonic_sort(keys, n_pad, false);
 
   // class segments of the sorted list
   for (int i = tid; i < n; i += kMergeThreads) {
@@ -230,6 +319,16 @@ __global__ __launch_bounds__(kMergeThreads) void nms_merge_kernel(const MergeArg
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float ws[2] = {0.f, 0.f}, wp[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int q = lane + 64 * h;
+      if (q < m) {
+        ws[h] = box[q][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wp[h][e] = ws[h] * box[q][e];
+      }
+    }
 
     u64 alive0 = (m >= 64) ? ~0ull : ((1ull << m) - 1ull);
     u64 alive1 = (m > 64) ? ((m - 64 >= 64) ? ~0ull : ((1ull << (m - 64)) - 1ull)) : 0ull;
@@ -261,19 +360,28 @@ __global__ __launch_bounds__(kMergeThreads) void nms_merge_kernel(const MergeArg
         }
         h0 = __ballot(hit[0]);
         h1 = __ballot(hit[1]);
-        // weighted mixture box (:272-274), sequential fp32 in candidate order
+        // weighted mixture box (:272-274), sequential fp32 in candidate order.  Lane q holds candidate q's score
+        // and its four products s*x1.. (rounded once, as the reference's `weights * boxes` does before the sum) in
+        // registers; the walk over the hit set pulls them with v_readlane — no LDS round trip per element.
         float wsum = 0.f, ax1 = 0.f, ay1 = 0.f, ax2 = 0.f, ay2 = 0.f;
         u64 w0 = h0, w1 = h1;
-        while (w0 | w1) {
-          int g;
-          if (w0) { g = __builtin_ctzll(w0); w0 &= w0 - 1; }
-          else    { g = 64 + __builtin_ctzll(w1); w1 &= w1 - 1; }
-          const float s = box[g][4];
-          wsum = wsum + s;
-          ax1 = ax1 + s * box[g][0];
-          ay1 = ay1 + s * box[g][1];
-          ax2 = ax2 + s * box[g][2];
-          ay2 = ay2 + s * box[g][3];
+        while (w0) {
+          const int g = __builtin_ctzll(w0);
+          w0 &= w0 - 1;
+          wsum = wsum + readlane_f(ws[0], g);
+          ax1 = ax1 + readlane_f(wp[0][0], g);
+          ay1 = ay1 + readlane_f(wp[0][1], g);
+          ax2 = ax2 + readlane_f(wp[0][2], g);
+          ay2 = ay2 + readlane_f(wp[0][3], g);
+        }
+        while (w1) {
+          const int g = __builtin_ctzll(w1);
+          w1 &= w1 - 1;
+          wsum = wsum + readlane_f(ws[1], g);
+          ax1 = ax1 + readlane_f(wp[1][0], g);
+          ay1 = ay1 + readlane_f(wp[1][1], g);
+          ax2 = ax2 + readlane_f(wp[1][2], g);
+          ay2 = ay2 + readlane_f(wp[1][3], g);
         }
         mx1 = __fdiv_rn(ax1, wsum);
         my1 = __fdiv_rn(ay1, wsum);
@@ -306,7 +414,7 @@ __global__ __launch_bounds__(kMergeThreads) void nms_merge_kernel(const MergeArg
   // ---- final order: conf descending, ties by class then pivot order (utils.py:289-291) -------------
   const int n_out = min(s_nout, a.stage_cap);
   __threadfence_block();
-  int f_pad = 1;
+  int f_pad = kMergeThreads;
   while (f_pad < n_out) f_pad <<= 1;
   for (int i = tid; i < f_pad; i += kMergeThreads) {
     u64 k = ~0ull;
@@ -320,7 +428,7 @@ __global__ __launch_bounds__(kMergeThreads) void nms_merge_kernel(const MergeArg
     s_keys[i] = k;
   }
   __syncthreads();
-  block_bitonic_sort(s_keys, f_pad);
+  block_sort_lds(s_keys, f_pad);
   for (int i = tid; i < n_out && i < a.cap; i += kMergeThreads) {
     const int slot = (int)(s_keys[i] & 0xfffffu);
     const float* o = stage + (long)slot * 8;
