@@ -25,7 +25,6 @@ constexpr int kLdsKeys = 8192;     // keys sorted in LDS; more survivors -> sort
 constexpr int kMaxClasses = 1024;
 constexpr int kMaxPerClassCap = 128;  // 2 candidates per lane
 constexpr int kMergeThreads = 1024;
-constexpr int kMergeWaves = kMergeThreads / 64;
 constexpr int kFilterRows = 64;
 
 // monotone float -> uint map (ascending), valid for every non-NaN float
@@ -251,11 +250,10 @@ __global__ __launch_bounds__(kMergeThreads) void nms_merge_kernel(const MergeArg
   __shared__ __attribute__((aligned(16))) u64 s_keys[kLdsKeys];
   __shared__ int s_seg_start[kMaxClasses];
   __shared__ int s_seg_len[kMaxClasses];
-  __shared__ float s_box[kMergeWaves][kMaxPerClassCap][5];  // x1,y1,x2,y2,conf per candidate
-  __shared__ int s_nout;
+  __shared__ int s_nout, s_nlist, s_next;
+  __shared__ int s_list[kMaxClasses];
 
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = min(a.counts[b], a.rows);
   if (n == 0) {
     if (tid == 0) a.out_count[b] = 0;
@@ -273,7 +271,7 @@ __global__ __launch_bounds__(kMergeThreads) void nms_merge_kernel(const MergeArg
     for (int i = n + tid; i < n_pad; i += kMergeThreads) keys[i] = ~0ull;
   }
   for (int c = tid; c < a.nc; c += kMergeThreads) s_seg_len[c] = 0;
-  if (tid == 0) s_nout = 0;
+  if (tid == 0) s_nout = s_nlist = s_next = 0;
   __syncthreads();
   if (keys == s_keys) block_sort_lds(keys, n_pad);
   else block_bitonic_sort(keys, n_pad, false);
@@ -285,20 +283,32 @@ __global__ __launch_bounds__(kMergeThreads) void nms_merge_kernel(const MergeArg
     if (i == n - 1 || key_class(keys[i + 1]) != c) s_seg_len[c] = i + 1;  // end for now
   }
   __syncthreads();
+  for (int c = tid; c < a.nc; c += kMergeThreads)
+    if (s_seg_len[c] > 0) s_list[atomicAdd(&s_nlist, 1)] = c;
+  __syncthreads();
 
   float* stage = a.stage + (long)b * a.stage_cap * 8;
   const float* pred = a.pred + (long)b * a.rows * a.no;
-  float(*box)[5] = s_box[wave];
 
-  for (int c = wave; c < a.nc; c += kMergeWaves) {
+  // classes are handed to the 16 waves through a work queue: survivors usually crowd into a few classes, and a static
+  // class -> wave map left most waves idle while one or two walked several long segments
+  for (;;) {
+    int qi = 0;
+    if (lane == 0) qi = atomicAdd(&s_next, 1);
+    qi = __builtin_amdgcn_readfirstlane(qi);
+    if (qi >= s_nlist) break;
+    const int c = s_list[qi];
     const int end = s_seg_len[c];
-    if (end == 0) continue;
     const int start = s_seg_start[c];
     const int seg_n = end - start;
     const int m = min(seg_n, a.max_per_class);                          // utils.py:247-250
-    // gather my (up to two) candidates: xywh -> xyxy (utils.py:57-60)
+    // gather my (up to two) candidates: xywh -> xyxy (utils.py:57-60).  Everything the merge loop needs stays in
+    // registers: lane q (and q + 64) owns candidate q's corners, area, score and score*corner products; the pivot's
+    // values are pulled with v_readlane, so the loop body has no LDS or memory round trip.
     int my_row[2] = {0, 0};
     float my_cconf[2] = {0.f, 0.f};
+    float bx[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, area[2] = {0.f, 0.f};
+    float ws[2] = {0.f, 0.f}, wp[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int q = lane + 64 * h;
@@ -307,26 +317,16 @@ __global__ __launch_bounds__(kMergeThreads) void nms_merge_kernel(const MergeArg
         const int r = key_row(k);
         const float* pr = pred + (long)r * a.no;
         const float x = pr[0], y = pr[1], w = pr[2], hh = pr[3];
-        box[q][0] = x - w / 2.f;
-        box[q][1] = y - hh / 2.f;
-        box[q][2] = x + w / 2.f;
-        box[q][3] = y + hh / 2.f;
-        box[q][4] = key_conf(k);
+        bx[h][0] = x - w / 2.f;
+        bx[h][1] = y - hh / 2.f;
+        bx[h][2] = x + w / 2.f;
+        bx[h][3] = y + hh / 2.f;
+        area[h] = (bx[h][2] - bx[h][0]) * (bx[h][3] - bx[h][1]);          // area2 of bbox_iou (:92)
+        ws[h] = key_conf(k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wp[h][e] = ws[h] * bx[h][e];
         my_row[h] = r;
         my_cconf[h] = pr[5 + c];
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float ws[2] = {0.f, 0.f}, wp[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int q = lane + 64 * h;
-      if (q < m) {
-        ws[h] = box[q][4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) wp[h][e] = ws[h] * box[q][e];
       }
     }
 
@@ -334,35 +334,35 @@ __global__ __launch_bounds__(kMergeThreads) void nms_merge_kernel(const MergeArg
     u64 alive1 = (m > 64) ? ((m - 64 >= 64) ? ~0ull : ((1ull << (m - 64)) - 1ull)) : 0ull;
     while (alive0 | alive1) {
       const int p = alive0 ? __builtin_ctzll(alive0) : 64 + __builtin_ctzll(alive1);
+      const int pl = p & 63;
+      const bool phi = p >= 64;
       const bool last = (__builtin_popcountll(alive0) + __builtin_popcountll(alive1)) == 1;
-      const float px1 = box[p][0], py1 = box[p][1], px2 = box[p][2], py2 = box[p][3];
+      const float px1 = readlane_f(phi ? bx[1][0] : bx[0][0], pl), py1 = readlane_f(phi ? bx[1][1] : bx[0][1], pl);
+      const float px2 = readlane_f(phi ? bx[1][2] : bx[0][2], pl), py2 = readlane_f(phi ? bx[1][3] : bx[0][3], pl);
+      const float pconf = readlane_f(phi ? ws[1] : ws[0], pl);
       float mx1 = px1, my1 = py1, mx2 = px2, my2 = py2;
       u64 h0 = 0, h1 = 0;
       if (last) {                                                        // :268-270 kept as is
-        if (p < 64) h0 = 1ull << p; else h1 = 1ull << (p - 64);
+        if (!phi) h0 = 1ull << pl; else h1 = 1ull << pl;
       } else {
+        const float area1 = (px2 - px1) * (py2 - py1) + 1e-16f;          // :91,:93
         bool hit[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const int q = lane + 64 * h;
           const bool live = ((h ? alive1 : alive0) >> lane) & 1ull;
           hit[h] = false;
           if (live) {                                                    // bbox_iou, utils.py:85-96
-            const float qx1 = box[q][0], qy1 = box[q][1], qx2 = box[q][2], qy2 = box[q][3];
-            const float iw = fminf(px2, qx2) - fmaxf(px1, qx1);
-            const float ih = fminf(py2, qy2) - fmaxf(py1, qy1);
+            const float iw = fminf(px2, bx[h][2]) - fmaxf(px1, bx[h][0]);
+            const float ih = fminf(py2, bx[h][3]) - fmaxf(py1, bx[h][1]);
             const float inter = fmaxf(iw, 0.f) * fmaxf(ih, 0.f);
-            const float area1 = (px2 - px1) * (py2 - py1) + 1e-16f;
-            const float area2 = (qx2 - qx1) * (qy2 - qy1);
-            const float uni = (area1 + area2) - inter;
+            const float uni = (area1 + area[h]) - inter;
             hit[h] = __fdiv_rn(inter, uni) > a.nms_thres;                // :271
           }
         }
         h0 = __ballot(hit[0]);
         h1 = __ballot(hit[1]);
-        // weighted mixture box (:272-274), sequential fp32 in candidate order.  Lane q holds candidate q's score
-        // and its four products s*x1.. (rounded once, as the reference's `weights * boxes` does before the sum) in
-        // registers; the walk over the hit set pulls them with v_readlane — no LDS round trip per element.
+        // weighted mixture box (:272-274), sequential fp32 in candidate order (products rounded once, as the
+        // reference's `weights * boxes` does before the sum)
         float wsum = 0.f, ax1 = 0.f, ay1 = 0.f, ax2 = 0.f, ay2 = 0.f;
         u64 w0 = h0, w1 = h1;
         while (w0) {
@@ -388,20 +388,19 @@ __global__ __launch_bounds__(kMergeThreads) void nms_merge_kernel(const MergeArg
         mx2 = __fdiv_rn(ax2, wsum);
         my2 = __fdiv_rn(ay2, wsum);
         if ((h0 | h1) == 0) {  // pivot does not overlap itself (the reference would spin forever): drop it
-          if (p < 64) h0 = 1ull << p; else h1 = 1ull << (p - 64);
+          if (!phi) h0 = 1ull << pl; else h1 = 1ull << pl;
         }
       }
       // the lane that owns the pivot emits the row
-      if (lane == (p & 63)) {
-        const int hsel = p >> 6;
+      if (lane == pl) {
         const int slot = atomicAdd(&s_nout, 1);
         if (slot < a.stage_cap) {
           float* o = stage + (long)slot * 8;
           o[0] = mx1; o[1] = my1; o[2] = mx2; o[3] = my2;
-          o[4] = box[p][4];
-          o[5] = hsel ? my_cconf[1] : my_cconf[0];
+          o[4] = pconf;
+          o[5] = phi ? my_cconf[1] : my_cconf[0];
           o[6] = (float)c;
-          o[7] = __int_as_float(hsel ? my_row[1] : my_row[0]);
+          o[7] = __int_as_float(phi ? my_row[1] : my_row[0]);
         }
       }
       alive0 &= ~h0;

@@ -13,5 +13,5 @@ out = (torch.empty((16, cap, 7), device=dev), torch.empty((16, cap), dtype=torch
 for _ in range(3): nms_launch(io, 0.1, 0.5, out, slot=0)
 torch.cuda.synchronize()
 d = out[0][:, cap - 1].cpu()
-print("cycles (100 MHz memtime ticks?) load, sort, classes, gather, sort2, write, n:")
+print("load, sort, classes, gather, sort2, write, nlist:")
 print(d.mean(0).tolist()); print(d[:4].tolist())
