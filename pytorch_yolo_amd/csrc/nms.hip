@@ -413,8 +413,10 @@ __global__ __launch_bounds__(kMergeThreads) void nms_merge_kernel(const MergeArg
   // ---- final order: conf descending, ties by class then pivot order (utils.py:289-291) -------------
   const int n_out = min(s_nout, a.stage_cap);
   __threadfence_block();
-  int f_pad = kMergeThreads;
+  int f_pad = 1;
   while (f_pad < n_out) f_pad <<= 1;
+  const bool small_final = f_pad <= 512;            // few kept rows: the plain LDS network (mostly wave-local) is cheaper
+  if (!small_final && f_pad < kMergeThreads) f_pad = kMergeThreads;
   for (int i = tid; i < f_pad; i += kMergeThreads) {
     u64 k = ~0ull;
     if (i < n_out) {
@@ -427,7 +429,8 @@ __global__ __launch_bounds__(kMergeThreads) void nms_merge_kernel(const MergeArg
     s_keys[i] = k;
   }
   __syncthreads();
-  block_sort_lds(s_keys, f_pad);
+  if (small_final) block_bitonic_sort(s_keys, f_pad, true);
+  else block_sort_lds(s_keys, f_pad);
   for (int i = tid; i < n_out && i < a.cap; i += kMergeThreads) {
     const int slot = (int)(s_keys[i] & 0xfffffu);
     const float* o = stage + (long)slot * 8;
