@@ -28,7 +28,12 @@ struct ConvArgs {
   int steps;    // kpad / 32
   uint32_t x_bytes, w_bytes;
   HeadDecodeArgs hd;   // DECODE instances only
-  int debug;    // timing ablations only (YOLO_CONV_DEBUG): 1 no pixel DMA, 2 no weight DMA, 4 no MFMA, 8 no epilogue
+  int debug;    // YOLO_CONV_DEBUG, tuning / ablation only (results are wrong with bits 1..8 set):
+                //   1 no pixel DMA   2 no weight DMA   4 no MFMA   8 no epilogue   16 no LDS-staged epilogue
+                //   32 no halo kernel   128 no 128x256 tiles   256 no loader waves   512 8-wave 256x256 tiles
+                //   1024 halo blocks of 256 couts   2048 32x32x16 MFMA in the gather kernel   8192 4-wave 128x128 / head tiles
+                //   16384 two-stage ring for the loader-wave tiles   32768 64x64 tiles for every tiny-grid 1x1 layer
+                //   65536 32x32x16 MFMA in the halo kernel
 };
 
 __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, uint32_t voffset) {
