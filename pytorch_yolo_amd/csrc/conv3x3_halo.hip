@@ -20,6 +20,7 @@ namespace {
 
 template <int TH, int TW, int BN, int WAVES_M, int WAVES_N, int CK, int HB, bool M16 = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv3x3_halo_kernel(const ConvArgs a) {
+  YOLO_BLOCK_STAMP(a);
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = TH * TW;
   constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N;

@@ -34,7 +34,55 @@ struct ConvArgs {
                 //   1024 halo blocks of 256 couts   2048 32x32x16 MFMA in the gather kernel   8192 4-wave 128x128 / head tiles
                 //   16384 two-stage ring for the loader-wave tiles   32768 64x64 tiles for every tiny-grid 1x1 layer
                 //   65536 32x32x16 MFMA in the halo kernel
+#ifdef YOLO_STAMPS
+  unsigned long long* stamps;   // diagnostic build only (tools/block_timeline.py): 4 words per workgroup
+#endif
 };
+
+// Diagnostic build (-DYOLO_STAMPS, never the shipped library): the first lane of every workgroup records when it
+// started and ended (s_memrealtime, 100 MHz), how many shader cycles that took (s_memtime) and where it ran
+// (HW_ID, XCC_ID).  The words go to a buffer nothing else reads (MI355X_MICROARCH.md, DVFS give-back item 6).
+#ifdef YOLO_STAMPS
+struct BlockStamp {
+  unsigned long long* base_;
+  unsigned long long* p;
+  unsigned long long t0, c0;
+  __device__ __forceinline__ unsigned long long* slot_() const {
+    return base_ + 4 * ((size_t)blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z)) + 1;
+  }
+  __device__ __forceinline__ explicit BlockStamp(unsigned long long* base) : base_(base), p(nullptr), t0(0), c0(0) {
+    if (base && threadIdx.x == 0) {
+      p = slot_() - 1;
+      t0 = __builtin_amdgcn_s_memrealtime();
+      c0 = __builtin_amdgcn_s_memtime();
+    }
+  }
+  __device__ __forceinline__ ~BlockStamp() {
+    // the workgroup ends when its last wave does: every wave's first lane folds its end time in
+    if (p) {
+      const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+      const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+      p[0] = t0;
+      p[2] = c1 - c0;
+      p[3] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+    }
+    if ((threadIdx.x & 63) == 0 && base_) atomicMax(slot_(), (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  }
+};
+inline unsigned long long* stamp_buffer_from_env() {
+  static long launch_idx = 0;
+  const char* e = getenv("YOLO_STAMP_PTR");
+  if (!e) return nullptr;
+  const char* st = getenv("YOLO_STAMP_STRIDE");   // words per launch (0 / unset: every launch writes at the base)
+  const long stride = st ? atol(st) : 0;
+  return (unsigned long long*)strtoull(e, nullptr, 0) + stride * launch_idx++;
+}
+#define YOLO_BLOCK_STAMP(args) BlockStamp block_stamp_((args).stamps)
+#define YOLO_SET_STAMPS(args) (args).stamps = stamp_buffer_from_env()
+#else
+#define YOLO_BLOCK_STAMP(args)
+#define YOLO_SET_STAMPS(args)
+#endif
 
 __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, uint32_t voffset) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16,

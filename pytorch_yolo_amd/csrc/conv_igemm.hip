@@ -21,6 +21,19 @@
 
 using namespace yolo_conv;
 
+// fragment read from LDS; the timing-only ablation build YOLO_ABL_NOLDS (tools/block_timeline.py) feeds the MFMAs
+// whatever the registers hold instead
+#ifdef YOLO_ABL_NOLDS
+__device__ __forceinline__ bf16x8 lds_frag_stub() {
+  bf16x8 v;
+  asm volatile("" : "=v"(v));
+  return v;
+}
+#define YOLO_LDS_FRAG(p) lds_frag_stub()
+#else
+#define YOLO_LDS_FRAG(p) (*reinterpret_cast<const bf16x8*>(p))
+#endif
+
 namespace {
 
 // BM pixels x BN couts block tile, WAVES_M x WAVES_N waves (4 or 8), K step BK (32 or 64), NS-stage LDS ring.
@@ -62,6 +75,7 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NP)) void conv_igemm_bf16
   static_assert(!DECODE || (!LDS_EPI && !MFMA16 && BM % NW == 0), "DECODE instances use the plain 32x32 accumulators");
   __shared__ __attribute__((aligned(16))) char smem[LDS_B];   // per stage: [BNL weight rows][BM pixel rows]
 
+  YOLO_BLOCK_STAMP(a);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -263,7 +277,9 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NP)) void conv_igemm_bf16
       else if (younger == 1) wait_vmcnt<1 * LPS>();
       else wait_vmcnt<0>();
     }
+#ifndef YOLO_ABL_NOBARRIER          // (timing-only ablation builds of tools/block_timeline.py)
     __builtin_amdgcn_s_barrier();   // everyone's stage s is in LDS; everyone finished reading stage s-1
+#endif
     const bool more = NP == 0 && s + NS - 1 < steps;
     int nb = buf + NS - 1;          // ring slot read in iteration s-1: free again after the barrier
     if (nb >= NS) nb -= NS;
@@ -286,7 +302,7 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NP)) void conv_igemm_bf16
           const char* const xk = xbuf + (kk ? (xo ^ 64) : xo);
           bf16x8 xf[NI16];
 #pragma unroll
-          for (int j = 0; j < NI16; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xk + j * 16 * ROWB);
+          for (int j = 0; j < NI16; ++j) xf[j] = YOLO_LDS_FRAG(xk + j * 16 * ROWB);
           if constexpr (NP > 0) {
             // register-lean order (3 waves per SIMD leave 168 registers): weight fragments one ahead of their MFMAs
             bf16x8 wcur = *reinterpret_cast<const bf16x8*>(wk);
@@ -301,7 +317,7 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NP)) void conv_igemm_bf16
           } else {
             bf16x8 wf[MI16];
 #pragma unroll
-            for (int i = 0; i < MI16; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(wk + i * 16 * ROWB);
+            for (int i = 0; i < MI16; ++i) wf[i] = YOLO_LDS_FRAG(wk + i * 16 * ROWB);
 #pragma unroll
             for (int i = 0; i < MI16; ++i)
 #pragma unroll
@@ -577,6 +593,7 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
   a.x_bytes = (uint32_t)x_bytes;
   a.w_bytes = (uint32_t)w_bytes;
   a.debug = conv_debug_flags;
+  YOLO_SET_STAMPS(a);
   if (hd) {   // head conv with the YOLOLayer decode as its epilogue: one 64-pixel x 256-cout tile per block
     a.hd = *hd;
     // 8 waves (2 blocks per CU -> 4 per SIMD) when cin allows 64-deep stages; bit 8192 selects the 4-wave forms
@@ -683,6 +700,7 @@ static int conv1_nchw(const float* x_nchw, int cin_real, const void* w_packed, c
   a.x_bytes = 0;
   a.w_bytes = 0;
   a.debug = 0;
+  YOLO_SET_STAMPS(a);
   const int rc = launch_conv1_nchw(a, x_nchw, cin_real, pool, (hipStream_t)s);
   if (rc == 1) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv1: shape not covered (3x3 s1, cout 16 or 32, bf16 out)");
   return rc;
