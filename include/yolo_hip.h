@@ -128,6 +128,24 @@ YOLO_API int yolo_stem_supported(int cin_real, int c1, int c2, int h, int w);
 YOLO_API int yolo_stem_fwd(const float* x_nchw, int cin_real, const void* w1_packed, const float* b1, int kpad1,
                            const void* w2_packed, const float* b2, void* y, const YoloConvDesc* d, yolo_stream_t s);
 
+/* ---- one MobileNetV2 inverted-residual block in one launch (torchvision InvertedResidual as the reference uses it,
+ *  models/yolov3_tiny_mobilenet.py:14-46):  y = [x +] proj1x1(relu6(dw3x3_stride(relu6(expand1x1(x))))), BN folded.
+ *  The expanded tensor (6x the input) and the depthwise output stay on the CU.  x, y: bf16 NHWC views.
+ *  ce = hidden rounded up to 32, cout_pad = cout rounded up to 16, dstride = yolo_mbconv_dstride(ce) bytes.
+ *    w_exp  bf16 [ce][48]: row = hidden channel, the first cin entries real, the rest zero (NULL: the block has
+ *           no expand conv, hidden == cin);  b_exp f32 [ce]
+ *    w_dw   f32 [9][ce] tap-major, b_dw f32 [ce]  (zero beyond hidden)
+ *    w_proj bf16 [cout_pad][dstride/2]: row = output channel, the first hidden entries real;  b_proj f32 [cout_pad]
+ *  has_res: y = x + ... (stride 1, cin == cout).  yolo_mbconv_supported(): cin <= 32, hidden <= 192, cout <= 64;
+ *  other blocks run as yolo_conv2d_fwd + yolo_dwconv3x3_fwd + yolo_conv2d_fwd. */
+typedef struct YoloMbconvDesc {
+  int32_t n, h, w, cin, in_c_total, in_c_offset, hidden, cout, out_c_total, out_c_offset, stride, has_expand, has_res, _pad;
+} YoloMbconvDesc;
+YOLO_API int yolo_mbconv_dstride(int ce);
+YOLO_API int yolo_mbconv_supported(int cin, int hidden, int cout, int stride);
+YOLO_API int yolo_mbconv_fwd(const void* x, const void* w_exp, const float* b_exp, const float* w_dw, const float* b_dw,
+                             const void* w_proj, const float* b_proj, void* y, const YoloMbconvDesc* d, yolo_stream_t s);
+
 /* ---- YOLOLayer.forward eval branch (models/yolo_layer.py:57-69,90-111).
  *  head: f32 NHWC [bs,ny,nx,head_c_total], channel a*(5+nc)+k.
  *  io:   f32 [bs, io_rows_total, 5+nc]; this head fills rows [io_row_offset, +na*ny*nx).
@@ -179,7 +197,7 @@ YOLO_API int yolo_letterbox_u8_fwd(const uint8_t* src, int h, int w, int c, int 
 
 /* ---- batched launcher: run a recorded list of ops with one FFI crossing (host overhead only). */
 enum { YOLO_OP_CONV = 1, YOLO_OP_MAXPOOL = 2, YOLO_OP_SPP = 3, YOLO_OP_DWCONV = 4, YOLO_OP_CONV1_NCHW = 5,
-       YOLO_OP_RESUNIT = 6, YOLO_OP_STEM = 7, YOLO_OP_HEAD_DECODE = 8, YOLO_OP_CONV1_POOL = 9 };
+       YOLO_OP_RESUNIT = 6, YOLO_OP_STEM = 7, YOLO_OP_HEAD_DECODE = 8, YOLO_OP_CONV1_POOL = 9, YOLO_OP_MBCONV = 10 };
 typedef struct YoloOp {
   int32_t kind, _pad;
   const void* x; const void* w; const float* bias; const void* residual; void* y; void* y_aux;
@@ -194,6 +212,10 @@ typedef struct YoloOp {
   /* HEAD_DECODE (yolo_head_decode_fwd): y = io, y_aux = p (nullable), conv = the head conv */
   float head_anchors_px[8]; float head_stride_px;
   int32_t head_na, head_nc, io_rows_total, io_row_offset, _pad2;
+  /* MBCONV (yolo_mbconv_fwd): w/bias = W_proj/b_proj, w_pre/bias_pre = W_expand/b_expand (NULL: no expand conv),
+     w_dw/bias_dw = the depthwise conv; geometry from conv (n,h,w,cin,views,cout,stride), hidden = kpad_pre,
+     has_res = conv.res_c_total != 0 */
+  const float* w_dw; const float* bias_dw;
 } YoloOp;
 YOLO_API int yolo_run_ops(const YoloOp* ops, int n_ops, yolo_stream_t s);
 

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("YOLO_HIP_LIB") or os.path.join(_HERE, "csrc", "libyol
 ACT_NONE, ACT_LEAKY01, ACT_RELU6 = 0, 1, 2
 DT_BF16, DT_F32 = 0, 1
 OP_CONV, OP_MAXPOOL, OP_SPP, OP_DWCONV, OP_CONV1_NCHW, OP_RESUNIT, OP_STEM, OP_HEAD_DECODE, OP_CONV1_POOL = 1, 2, 3, 4, 5, 6, 7, 8, 9
+OP_MBCONV = 10
 
 
 class YoloConvDesc(C.Structure):
@@ -32,7 +33,14 @@ class YoloOp(C.Structure):
                 ("w_pre", C.c_void_p), ("bias_pre", C.c_void_p), ("kpad_pre", C.c_int32), ("cout_pad_pre", C.c_int32),
                 ("head_anchors_px", C.c_float * 8), ("head_stride_px", C.c_float),
                 ("head_na", C.c_int32), ("head_nc", C.c_int32), ("io_rows_total", C.c_int32),
-                ("io_row_offset", C.c_int32), ("_pad2", C.c_int32)]
+                ("io_row_offset", C.c_int32), ("_pad2", C.c_int32),
+                ("w_dw", C.c_void_p), ("bias_dw", C.c_void_p)]
+
+
+class YoloMbconvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "n", "h", "w", "cin", "in_c_total", "in_c_offset", "hidden", "cout", "out_c_total", "out_c_offset",
+        "stride", "has_expand", "has_res", "_pad")]
 
 
 # symbol -> (restype, argtypes); kept in one table so tests can check it against the header
@@ -51,6 +59,9 @@ SIGNATURES = {
                                 C.POINTER(YoloConvDesc), C.c_void_p]),
     "yolo_resunit_supported": (C.c_int, [C.c_int] * 3),
     "yolo_resunit_fwd": (C.c_int, [C.c_void_p] * 7 + [C.POINTER(YoloConvDesc), C.c_int, C.c_int, C.c_void_p]),
+    "yolo_mbconv_dstride": (C.c_int, [C.c_int]),
+    "yolo_mbconv_supported": (C.c_int, [C.c_int] * 4),
+    "yolo_mbconv_fwd": (C.c_int, [C.c_void_p] * 8 + [C.POINTER(YoloMbconvDesc), C.c_void_p]),
     "yolo_dwconv3x3_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 12 + [C.c_void_p]),
     "yolo_maxpool_fwd": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 14 + [C.c_void_p]),
     "yolo_spp_fwd": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),

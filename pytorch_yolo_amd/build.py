@@ -21,6 +21,7 @@ SOURCES = {
     "conv3x3_halo.hip": [],
     "conv_resunit.hip": [],
     "conv_stem.hip": [],
+    "conv_mbconv.hip": [],
     "pointwise.hip": [],
     "preprocess.hip": ["-ffp-contract=off"],
     "nms.hip": ["-ffp-contract=off"],

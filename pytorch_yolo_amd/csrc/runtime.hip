@@ -53,6 +53,14 @@ extern "C" int yolo_run_ops(const YoloOp* ops, int n_ops, yolo_stream_t s) {
         rc = yolo_head_decode_fwd(o.x, o.w, o.bias, &d, o.head_anchors_px, o.head_na, o.head_nc, o.head_stride_px, (float*)o.y,
                                   o.io_rows_total, o.io_row_offset, (float*)o.y_aux, s);
         break;
+      case YOLO_OP_MBCONV: {
+        YoloMbconvDesc m;
+        m.n = d.n, m.h = d.h, m.w = d.w, m.cin = d.cin, m.in_c_total = d.in_c_total, m.in_c_offset = d.in_c_offset;
+        m.hidden = o.kpad_pre, m.cout = d.cout, m.out_c_total = d.out_c_total, m.out_c_offset = d.out_c_offset;
+        m.stride = d.stride, m.has_expand = o.w_pre != nullptr, m.has_res = d.res_c_total != 0, m._pad = 0;
+        rc = yolo_mbconv_fwd(o.x, o.w_pre, o.bias_pre, o.w_dw, o.bias_dw, o.w, o.bias, o.y, &m, s);
+        break;
+      }
       default:
         return yolo_set_error(YOLO_E_ARG, "run_ops: op %d has unknown kind %d", i, o.kind);
     }

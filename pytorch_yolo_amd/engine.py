@@ -28,7 +28,7 @@ import torch
 
 from . import kernels as K
 from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU6, DT_BF16, DT_F32, OP_CONV, OP_CONV1_NCHW, OP_DWCONV,
-                   OP_CONV1_POOL, OP_HEAD_DECODE, OP_MAXPOOL, OP_RESUNIT, OP_SPP, OP_STEM, YoloOp)
+                   OP_CONV1_POOL, OP_MBCONV, OP_HEAD_DECODE, OP_MAXPOOL, OP_RESUNIT, OP_SPP, OP_STEM, YoloOp)
 
 # which residual-unit widths run as ONE launch (bit mask of C: 64 | 128 | 256); see DESIGN.md §3.1d for the
 # measurements behind the default.  YOLO_FUSE_RESUNIT overrides it (tuning only).
@@ -226,9 +226,34 @@ class Plan:
             if (fuse_mask & c) and K.resunit_supported(c, res.h, res.w):
                 nd.attrs["fuse_pre"] = pa
                 pa.attrs["fused_away"] = True
+        # 2c. MobileNetV2 inverted-residual blocks (1x1 expand + ReLU6, depthwise 3x3 + ReLU6, linear 1x1 [+ x]) with
+        #     few channels, i.e. the large maps: one launch (yolo_mbconv_fwd), the 6x-expanded tensor and the
+        #     depthwise output never exist in HBM; the output gets its own buffer (neighbouring tiles read x)
+        if os.environ.get("YOLO_FUSE_MBCONV", "1") == "1":
+            for nd in nodes:
+                if (nd.kind != "conv" or "up_into" in nd.attrs or len(nd.outs) != 1 or nd.outs[0].f32
+                        or nd.attrs["act"] != "none" or nd.attrs["stride"] != 1 or nd.attrs["weight"][0].shape[2] != 1):
+                    continue
+                dsym = nd.srcs[0]
+                dwn = dsym.producer
+                if dwn is None or dwn.kind != "dwconv" or dwn.attrs["act"] != "relu6" or len(dsym.consumers) != 1 or dsym.buf is not None:
+                    continue
+                esym = dwn.srcs[0]
+                ex = esym.producer
+                has_exp = (ex is not None and ex.kind == "conv" and ex.attrs["weight"][0].shape[2] == 1 and ex.attrs["act"] == "relu6"
+                           and ex.attrs["stride"] == 1 and not ex.attrs["has_res"] and len(ex.outs) == 1 and "up_into" not in ex.attrs
+                           and len(esym.consumers) == 1 and esym.buf is None and not esym.f32)
+                x = ex.srcs[0] if has_exp else esym
+                if x is self.rec.input or x.f32 or (nd.attrs["has_res"] and nd.srcs[1] is not x):
+                    continue
+                if K.mbconv_supported(x.c, esym.c, nd.attrs["weight"][0].shape[0], dwn.attrs["stride"]):
+                    nd.attrs["mb_pre"] = (ex if has_exp else None, dwn, x)
+                    dwn.attrs["fused_away"] = True
+                    if has_exp:
+                        ex.attrs["fused_away"] = True
         # 3. residual adds are written in place of the residual input when it is dead afterwards
         for nd in nodes:
-            if nd.kind == "conv" and nd.attrs["has_res"] and "fuse_pre" not in nd.attrs:
+            if nd.kind == "conv" and nd.attrs["has_res"] and "fuse_pre" not in nd.attrs and "mb_pre" not in nd.attrs:
                 res, y = nd.srcs[1], nd.outs[0]
                 dead = all(order[id(cn)] <= order[id(nd)] for cn in res.consumers)
                 if dead and y.buf is None and res.buf is not None and not y.f32:
@@ -390,6 +415,24 @@ class Plan:
                 op.io_rows_total, op.io_row_offset = self.rows_total, hd["row"]
                 hd["op"] = len(ops)
                 ops.append(op)
+            elif nd.kind == "conv" and "mb_pre" in nd.attrs:
+                ex, dwn, x = nd.attrs["mb_pre"]
+                y = nd.outs[0]
+                hidden = dwn.srcs[0].c
+                we_b = ex.attrs["weight"] if ex is not None else (None, None)
+                packed = K.pack_mbconv(we_b[0], we_b[1], *dwn.attrs["weight"], *nd.attrs["weight"])
+                we, be, wd, bd, wp, bp = (None if t is None else self._dev(t) for t in packed)
+                op = YoloOp()
+                op.kind = OP_MBCONV
+                op.x, op.y = x.buf.tensor.data_ptr(), y.buf.tensor.data_ptr()
+                op.w, op.bias, op.w_dw, op.bias_dw = wp.data_ptr(), bp.data_ptr(), wd.data_ptr(), bd.data_ptr()
+                op.w_pre, op.bias_pre = (we.data_ptr(), be.data_ptr()) if we is not None else (None, None)
+                op.kpad_pre = hidden
+                d = op.conv
+                d.n, d.h, d.w, d.cin, d.in_c_total, d.in_c_offset = x.n, x.h, x.w, x.c, x.buf.c_total, x.c_offset
+                d.ho, d.wo, d.cout, d.out_c_total, d.out_c_offset = y.h, y.w, y.c, y.buf.c_total, y.c_offset
+                d.ksize, d.stride, d.res_c_total = 3, dwn.attrs["stride"], 1 if nd.attrs["has_res"] else 0
+                ops.append(op)
             elif nd.kind == "conv" and "fuse_pre" in nd.attrs:
                 pa = nd.attrs["fuse_pre"]
                 x, y, mid = nd.srcs[1], nd.outs[0], nd.srcs[0]
@@ -547,6 +590,9 @@ class Plan:
                 total += 2.0 * d.n * d.h * d.w * (d.cout * d.cin) * 10
             elif op.kind == OP_DWCONV:
                 total += 2.0 * d.n * d.ho * d.wo * d.cin * 9
+            elif op.kind == OP_MBCONV:                       # expand at the input size, depthwise + projection at the output size
+                hid = op.kpad_pre
+                total += (2.0 * d.n * d.h * d.w * d.cin * hid if op.w_pre else 0.0) + 2.0 * d.n * d.ho * d.wo * hid * (9 + d.cout)
         return total
 
     def new_outputs(self):

@@ -10,10 +10,10 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU6, DT_BF16, DT_F32, YoloConvDesc,
+from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU6, DT_BF16, DT_F32, YoloConvDesc, YoloMbconvDesc,
                    check, load)
 
-__all__ = ["stream_ptr", "pack_input", "conv2d", "stem", "resunit", "resunit_supported", "maxpool", "spp", "dwconv3x3", "decode", "head_decode", "head_decode_supported",
+__all__ = ["stream_ptr", "pack_input", "conv2d", "stem", "resunit", "resunit_supported", "maxpool", "spp", "dwconv3x3", "mbconv", "mbconv_supported", "pack_mbconv", "decode", "head_decode", "head_decode_supported",
            "nms_merge", "pack_conv_weight", "roundup", "run_ops"]
 
 
@@ -123,6 +123,49 @@ def dwconv3x3(x, w9c, bias, y, *, n, h, w, c, in_view, out_view, stride, act):
     ho, wo = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
     check(load().yolo_dwconv3x3_fwd(_ptr(x), _ptr(w9c), _ptr(bias), _ptr(y), n, h, w, c, in_view[0], in_view[1],
                                     ho, wo, out_view[0], out_view[1], stride, act, stream_ptr()), "dwconv3x3")
+    return y
+
+
+def mbconv_supported(cin: int, hidden: int, cout: int, stride: int) -> bool:
+    return bool(load().yolo_mbconv_supported(cin, hidden, cout, stride))
+
+
+def pack_mbconv(w_exp, b_exp, w_dw, b_dw, w_proj, b_proj):
+    """Folded weights of one inverted-residual block -> the images yolo_mbconv_fwd reads (host tensors).
+    w_exp [hidden,cin,1,1] or None, w_dw [hidden,1,3,3], w_proj [cout,hidden,1,1]; biases f32.
+    Returns (we bf16 [ce,48] | None, be f32 [ce] | None, wd f32 [9,ce], bd f32 [ce], wp bf16 [cout_pad,dstride/2],
+    bp f32 [cout_pad])."""
+    hidden, cout = w_dw.shape[0], w_proj.shape[0]
+    ce, cop = roundup(hidden, 32), roundup(cout, 16)
+    dstride = load().yolo_mbconv_dstride(ce)
+    we = be = None
+    if w_exp is not None:
+        cin = w_exp.shape[1]
+        we = torch.zeros((ce, 48), dtype=torch.float32)
+        we[:hidden, :cin] = w_exp.detach().float().cpu().reshape(hidden, cin)
+        we = we.to(torch.bfloat16).contiguous()
+        be = torch.zeros(ce, dtype=torch.float32)
+        be[:hidden] = b_exp.detach().float().cpu()
+    wd = torch.zeros((9, ce), dtype=torch.float32)
+    wd[:, :hidden] = w_dw.detach().float().cpu().reshape(hidden, 9).t()
+    bd = torch.zeros(ce, dtype=torch.float32)
+    bd[:hidden] = b_dw.detach().float().cpu()
+    wp = torch.zeros((cop, dstride // 2), dtype=torch.float32)
+    wp[:cout, :hidden] = w_proj.detach().float().cpu().reshape(cout, hidden)
+    bp = torch.zeros(cop, dtype=torch.float32)
+    bp[:cout] = b_proj.detach().float().cpu()
+    return we, be, wd.contiguous(), bd, wp.to(torch.bfloat16).contiguous(), bp
+
+
+def mbconv(x, packed, y, *, n, h, w, cin, hidden, cout, in_view, out_view, stride, has_res):
+    """One MobileNetV2 inverted-residual block (yolo_mbconv_fwd); ``packed`` = pack_mbconv(...) moved to the device."""
+    we, be, wd, bd, wp, bp = packed
+    _need_cuda(x, we, be, wd, bd, wp, bp, y)
+    d = YoloMbconvDesc(n=n, h=h, w=w, cin=cin, in_c_total=in_view[0], in_c_offset=in_view[1], hidden=hidden, cout=cout,
+                       out_c_total=out_view[0], out_c_offset=out_view[1], stride=stride,
+                       has_expand=0 if we is None else 1, has_res=1 if has_res else 0)
+    check(load().yolo_mbconv_fwd(_ptr(x), _ptr(we), _ptr(be), _ptr(wd), _ptr(bd), _ptr(wp), _ptr(bp), _ptr(y),
+                                 C.byref(d), stream_ptr()), "mbconv")
     return y
 
 

@@ -206,6 +206,72 @@ def test_fused_residual_unit(n, h, w, c, use_aux):
     assert float(diff.max()) <= 0.07 and float((diff > 0).float().mean()) < 0.25, (float(diff.max()), float((diff > 0).float().mean()))
 
 
+@pytest.mark.parametrize("n,h,w,cin,hidden,cout,stride", [
+    (2, 26, 30, 32, 32, 16, 1),       # first MobileNetV2 block: no expand conv
+    (2, 40, 36, 16, 96, 24, 2),       # expand + stride 2, odd tile remainders
+    (1, 23, 19, 24, 144, 24, 1),      # residual, hidden not a multiple of 32, odd sizes
+    (3, 33, 41, 24, 144, 32, 2),
+    (2, 16, 24, 32, 192, 32, 1),      # residual
+    (1, 52, 52, 32, 192, 64, 2),
+    (4, 104, 104, 24, 144, 24, 1)])   # more tiles than workgroups: the persistent loop and its prefetch
+def test_fused_inverted_residual(n, h, w, cin, hidden, cout, stride):
+    """yolo_mbconv_fwd (expand 1x1 -> depthwise 3x3 -> projection 1x1 [-> add] in one launch) against fp32 torch on
+    the same bf16-rounded operands (both intermediates rounded to bf16 like the stored tensors of the three-launch
+    path) and against the three-launch path itself; channel-offset views, image borders inside a tile and the
+    zero padding of the EXPANDED map are exercised."""
+    from pytorch_yolo_amd import kernels as K
+    from pytorch_yolo_amd._lib import ACT_NONE, ACT_RELU6
+    assert K.mbconv_supported(cin, hidden, cout, stride)
+    has_exp, has_res = hidden != cin, stride == 1 and cin == cout
+    g = torch.Generator().manual_seed(cin * 7 + hidden + h)
+    x = torch.randn(n, cin, h, w, generator=g).clamp_(-3, 3)
+    we = torch.randn(hidden, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5 if has_exp else None
+    be = torch.randn(hidden, generator=g) * 0.5 if has_exp else None
+    wd = torch.randn(hidden, 1, 3, 3, generator=g) * (2.0 / 9) ** 0.5
+    bd = torch.randn(hidden, generator=g) * 0.5
+    wp = torch.randn(cout, hidden, 1, 1, generator=g) * (1.0 / hidden) ** 0.5
+    bp = torch.randn(cout, generator=g) * 0.1
+    in_ct, in_co, out_ct, out_co = cin + 16, 8, cout + 8, 4
+    xin = torch.zeros(n, h, w, in_ct, dtype=torch.bfloat16, device=DEV)
+    xin[..., in_co:in_co + cin] = _nhwc(x)
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    y = torch.full((n, ho, wo, out_ct), -77.0, dtype=torch.bfloat16, device=DEV)
+    packed = tuple(None if t is None else t.to(DEV) for t in K.pack_mbconv(we, be, wd, bd, wp, bp))
+    K.mbconv(xin, packed, y, n=n, h=h, w=w, cin=cin, hidden=hidden, cout=cout, in_view=(in_ct, in_co),
+             out_view=(out_ct, out_co), stride=stride, has_res=has_res)
+    torch.cuda.synchronize()
+    xr = _bf16r(x)
+    e = _bf16r(F.conv2d(xr, _bf16r(we), be).clamp(0, 6)) if has_exp else xr
+    dd = _bf16r(F.conv2d(e, wd, bd, stride=stride, padding=1, groups=hidden).clamp(0, 6))
+    ref = F.conv2d(dd, _bf16r(wp), bp)
+    if has_res:
+        ref = ref + xr
+    got = _nchw(y[..., out_co:out_co + cout])
+    torch.testing.assert_close(got, ref, rtol=1e-2, atol=3e-2)
+    assert torch.all(y[..., :out_co] == -77.0) and torch.all(y[..., out_co + cout:] == -77.0)
+    # the three-launch path on the same operands
+    cur, ct, co = xin, in_ct, in_co
+    if has_exp:
+        w1p, b1p, kpad1, cpad1 = K.pack_conv_weight(we, be, cin)
+        eb = torch.empty(n, h, w, hidden, dtype=torch.bfloat16, device=DEV)
+        d1 = K.conv_desc(n=n, h=h, w=w, cin=cin, in_c_total=in_ct, in_c_offset=in_co, cout=hidden, out_c_total=hidden,
+                         out_c_offset=0, ksize=1, stride=1, act=ACT_RELU6, kpad=kpad1, cout_pad=cpad1)
+        K.conv2d(xin, w1p.to(DEV), b1p.to(DEV), eb, d1)
+        cur, ct, co = eb, hidden, 0
+    db = torch.empty(n, ho, wo, hidden, dtype=torch.bfloat16, device=DEV)
+    K.dwconv3x3(cur, wd.reshape(hidden, 9).t().contiguous().to(DEV), bd.to(DEV), db, n=n, h=h, w=w, c=hidden,
+                in_view=(ct, co), out_view=(hidden, 0), stride=stride, act=ACT_RELU6)
+    w3p, b3p, kpad3, cpad3 = K.pack_conv_weight(wp, bp, hidden)
+    y3 = torch.empty(n, ho, wo, cout, dtype=torch.bfloat16, device=DEV)
+    d3 = K.conv_desc(n=n, h=ho, w=wo, cin=hidden, in_c_total=hidden, in_c_offset=0, cout=cout, out_c_total=cout,
+                     out_c_offset=0, ksize=1, stride=1, act=ACT_NONE, kpad=kpad3, cout_pad=cpad3,
+                     res=(in_ct, in_co) if has_res else (0, 0))
+    K.conv2d(db, w3p.to(DEV), b3p.to(DEV), y3, d3, residual=xin if has_res else None)
+    torch.cuda.synchronize()
+    diff = (y[..., out_co:out_co + cout].float() - y3.float()).abs()
+    assert float(diff.max()) <= 0.07 and float((diff > 0).float().mean()) < 0.25, (float(diff.max()), float((diff > 0).float().mean()))
+
+
 @pytest.mark.parametrize("n,h,w,cin,k,nc,act", [(2, 20, 20, 256, 1, 80, "leaky"), (3, 13, 13, 512, 1, 80, "none"),
                                                   (1, 10, 12, 64, 3, 80, "leaky"), (2, 8, 8, 72, 1, 3, "none"),
                                                   (1, 26, 26, 128, 1, 20, "none"), (2, 14, 14, 96, 1, 80, "leaky")])

@@ -13,7 +13,7 @@ import torch
 import _cases as C
 from pytorch_yolo_amd import YOLOv3SPP, YOLOv3Tiny, YOLOv3TinyMobile, _lib, engine
 from pytorch_yolo_amd import kernels as K
-from pytorch_yolo_amd._lib import OP_CONV, OP_CONV1_NCHW, OP_CONV1_POOL, OP_HEAD_DECODE, OP_RESUNIT, OP_STEM, OP_DWCONV, OP_MAXPOOL, OP_SPP
+from pytorch_yolo_amd._lib import OP_MBCONV, OP_CONV, OP_CONV1_NCHW, OP_CONV1_POOL, OP_HEAD_DECODE, OP_RESUNIT, OP_STEM, OP_DWCONV, OP_MAXPOOL, OP_SPP
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -35,9 +35,14 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     # 23 int32 fields in YoloConvDesc; YoloOp = 2 int32 + 6 pointers + desc (+4 pad) + 2 pointers + 2 int32 + 9 float + 5 int32
+    # + 2 pointers
     assert ctypes.sizeof(_lib.YoloConvDesc) == 23 * 4
-    assert ctypes.sizeof(_lib.YoloOp) == 8 + 6 * 8 + 23 * 4 + 4 + 2 * 8 + 2 * 4 + 9 * 4 + 5 * 4
-    assert _lib.YoloOp.w_pre.offset == 152 and _lib.YoloOp.kpad_pre.offset == 168
+    assert ctypes.sizeof(_lib.YoloMbconvDesc) == 14 * 4
+    assert ctypes.sizeof(_lib.YoloOp) == 8 + 6 * 8 + 23 * 4 + 4 + 2 * 8 + 2 * 4 + 9 * 4 + 5 * 4 + 2 * 8
+    assert _lib.YoloOp.w_pre.offset == 152 and _lib.YoloOp.kpad_pre.offset == 168 and _lib.YoloOp.w_dw.offset == 232
+    mb = text_mb = open(os.path.join(ROOT, "include", "yolo_hip.h")).read()
+    mb = mb[mb.index("typedef struct YoloMbconvDesc {"):mb.index("} YoloMbconvDesc;")]
+    assert re.findall(r"\b([a-z_0-9]+)\s*[,;]", mb.split("{", 1)[1]) == [f for f, _ in _lib.YoloMbconvDesc._fields_]
     text = open(os.path.join(ROOT, "include", "yolo_hip.h")).read()
     body = text[text.index("typedef struct YoloConvDesc {"):text.index("} YoloConvDesc;")]
     fields = re.findall(r"\b([a-z_0-9]+)\s*[,;]", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
@@ -147,8 +152,15 @@ def test_planner_tiny_and_mobile():
     assert plan.rows_total == 2535 and [h["stride"] for h in plan.heads] == [16.0, 32.0]
     plan = _dry_plan(YOLOv3TinyMobile().eval(), 416)
     kinds = [o.kind for o in _ops(plan)]
-    assert kinds.count(OP_DWCONV) == 17 and kinds.count(OP_CONV) == 38 and kinds.count(OP_HEAD_DECODE) == 2 and not plan.fused_input   # stride-2 stem: generic path
-    assert sum(1 for o in _ops(plan) if o.kind == OP_CONV and o.residual) == 10          # MobileNetV2 identity shortcuts
+    # the seven inverted-residual blocks on the 208..52 maps (hidden <= 192) are one launch each (yolo_mbconv_fwd); the ten
+    # wider ones keep three launches
+    mb = [o for o in _ops(plan) if o.kind == OP_MBCONV]
+    assert [(o.conv.cin, o.kpad_pre, o.conv.cout, o.conv.stride, o.conv.h, bool(o.w_pre), o.conv.res_c_total) for o in mb] == [
+        (32, 32, 16, 1, 208, False, 0), (16, 96, 24, 2, 208, True, 0), (24, 144, 24, 1, 104, True, 1), (24, 144, 32, 2, 104, True, 0),
+        (32, 192, 32, 1, 52, True, 1), (32, 192, 32, 1, 52, True, 1), (32, 192, 64, 2, 52, True, 0)]
+    assert all(o.y != o.x and o.w_dw and o.bias_dw for o in mb)
+    assert kinds.count(OP_DWCONV) == 10 and kinds.count(OP_CONV) == 25 and kinds.count(OP_HEAD_DECODE) == 2 and not plan.fused_input   # stride-2 stem: generic path
+    assert sum(1 for o in _ops(plan) if o.kind == OP_CONV and o.residual) == 7           # MobileNetV2 identity shortcuts of the wide blocks
 
 
 def test_unsupported_widths_fail_loudly():

@@ -85,6 +85,12 @@ def main():
             tot_fl += fl
             by = M * Cc * 2 * 3
             print(f"{i:3d} {'resunit':7} {M:9d} {Cc:5d} {Cc * 5:5d} 3 1 {ms:8.4f} {fl / ms / 1e9:8.1f} {by / ms / 1e6:7.0f}  {'aux' if op.y_aux else ''}")
+        elif op.kind == 10:     # OP_MBCONV: hidden in the K column, bytes = x read + y written
+            M, hid = d.n * d.ho * d.wo, op.kpad_pre
+            fl = (2.0 * d.n * d.h * d.w * d.cin * hid if op.w_pre else 0.0) + 2.0 * M * hid * (9 + d.cout)
+            tot_fl += fl
+            by = d.n * d.h * d.w * d.cin * 2 + M * d.cout * 2
+            print(f"{i:3d} {'mbconv':7} {M:9d} {d.cout:5d} {hid:5d} 3 {d.stride:1d} {ms:8.4f} {fl / ms / 1e9:8.1f} {by / ms / 1e6:7.0f}  {'res' if d.res_c_total else ''}")
         else:
             kind = {OP_MAXPOOL: "pool", OP_SPP: "spp", OP_DWCONV: "dwconv"}[op.kind]
             by = d.n * d.h * d.w * d.cin * 2 * (4 if op.kind == OP_SPP else 2)
