@@ -50,7 +50,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void mb
   static_assert(P % 16 == 0, "tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
-  constexpr int nt = NT, nw = NT / 64;                   // 512 threads (two workgroups per CU) or 1024
+  constexpr int nt = NT, nw = NT / 64;                   // 256 / 512 threads (four / two workgroups per CU) or 1024
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // E rows: +8 bytes when the expand epilogue writes them (16 lanes = 16 pixels per ds_write_b64: an odd multiple of
   // 8 bytes apart spreads them over the banks); without an expand conv the rows take 16-byte tile loads
@@ -266,6 +266,7 @@ int launch(const MbArgs& a0, hipStream_t s) {
   YOLO_REQUIRE(lds <= 160 * 1024, "mbconv: %zu bytes of LDS needed", lds);
   // persistent workgroups; the phases of one tile (load, expand, depthwise, project) are latency chains, so a CU
   // needs more than 8 waves in flight: two 512-thread workgroups per CU when the LDS allows, else one of 1024 threads
+  if (lds <= 40 * 1024) return launch_nt<S, TH, TW, EXPAND, 256>(a, lds, 1024, s);   // four per CU: phases of four tiles overlap
   if (lds <= 80 * 1024) return launch_nt<S, TH, TW, EXPAND, 512>(a, lds, 512, s);
   return launch_nt<S, TH, TW, EXPAND, 1024>(a, lds, 256, s);
 }
