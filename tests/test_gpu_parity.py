@@ -607,6 +607,37 @@ def test_mobilenet_variant_vs_oracle():
     _assert_model_close(io.cpu(), io_ref, "mobile_96x128", score_max=3e-2, score_rms=4e-3)
 
 
+def test_mobilenet_fused_blocks_match_three_launch_path(monkeypatch):
+    """Whole YOLOv3TinyMobile at 416x416, 8 images: the plan with the seven inverted-residual blocks fused
+    (yolo_mbconv_fwd, thousands of tiles per launch: persistent loops, 4 / 2 / 1 workgroups per CU) against the plan
+    that runs every block as expand conv + depthwise conv + projection conv.  Same rounding points, so the decoded
+    boxes and scores agree to bf16 summation-order noise."""
+    from pytorch_yolo_amd import YOLOv3TinyMobile
+    from pytorch_yolo_amd._lib import OP_MBCONV
+    from pytorch_yolo_amd.utils.synthetic import synth_images, synth_state_dict
+    x = synth_images(8, 416, 416, 11).to(DEV)
+    outs, n_fused = [], []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("YOLO_FUSE_MBCONV", fuse)
+        model = YOLOv3TinyMobile(n_class=80).eval()
+        model.load_state_dict(synth_state_dict(model.state_dict(), 1234, n_class=80))
+        model = model.to(DEV)
+        with torch.no_grad():
+            io, _ = model(x)
+        plan = model.plan_for(x)
+        plan = plan.subs[0] if hasattr(plan, "subs") else plan          # (sub-batch streams: every sub-plan has the same list)
+        n_fused.append(sum(1 for i in range(plan.n_ops) if plan.op_array[i].kind == OP_MBCONV))
+        outs.append(io.float().cpu())
+    assert n_fused == [7, 0]
+    a, b = outs
+    assert torch.isfinite(a).all() and a.shape == (8, 3 * (26 * 26 + 13 * 13), 85)
+    xy_err = (a[..., :2] - b[..., :2]).abs().max().item()                       # pixels
+    wh_err = ((a[..., 2:4] - b[..., 2:4]).abs() / b[..., 2:4].clamp_min(1.0)).max().item()   # relative: w, h = exp(t) * anchor
+    score_err = (a[..., 4:] - b[..., 4:]).abs().max().item()
+    assert xy_err < 0.5 and wh_err < 2e-2 and score_err < 3e-2, (xy_err, wh_err, score_err)
+    assert (a[..., 4:] - b[..., 4:]).pow(2).mean().sqrt().item() < 2e-3
+
+
 def test_downsample_sub_is_pre_add():
     from pytorch_yolo_amd.models.yolov3_spp import DownSample
     from pytorch_yolo_amd.utils.synthetic import synth_images, synth_state_dict
