@@ -255,14 +255,19 @@ int launch_nt(const MbArgs& a, size_t lds, int slots, hipStream_t s) {
 }
 
 template <int S, int TH, int TW, bool EXPAND>
-int launch(const MbArgs& a0, hipStream_t s) {
+size_t lds_bytes(const MbArgs& a) {
   constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3, HP = IH * IW, HPP = (HP + 15) / 16 * 16, P = TH * TW;
+  return (size_t)(EXPAND ? HPP * kXStride : 0) + (size_t)HPP * (a.ce * 2 + (EXPAND ? 8 : 0)) + (size_t)P * a.dstride +
+         (size_t)(EXPAND ? a.ce * kXStride : 0) + (size_t)a.cop * a.dstride + (size_t)(a.ce + a.cop) * 4;
+}
+
+template <int S, int TH, int TW, bool EXPAND>
+int launch(const MbArgs& a0, hipStream_t s) {
   MbArgs a = a0;
   a.tiles_x = (a.wo + TW - 1) / TW;
   a.tiles_y = (a.ho + TH - 1) / TH;
   a.n_tiles = a.n * a.tiles_x * a.tiles_y;
-  const size_t lds = (size_t)(EXPAND ? HPP * kXStride : 0) + (size_t)HPP * (a.ce * 2 + (EXPAND ? 8 : 0)) + (size_t)P * a.dstride +
-                     (size_t)(EXPAND ? a.ce * kXStride : 0) + (size_t)a.cop * a.dstride + (size_t)(a.ce + a.cop) * 4;
+  const size_t lds = lds_bytes<S, TH, TW, EXPAND>(a);
   YOLO_REQUIRE(lds <= 160 * 1024, "mbconv: %zu bytes of LDS needed", lds);
   // persistent workgroups; the phases of one tile (load, expand, depthwise, project) are latency chains, so a CU
   // needs more than 8 waves in flight: two 512-thread workgroups per CU when the LDS allows, else one of 1024 threads
@@ -270,6 +275,11 @@ int launch(const MbArgs& a0, hipStream_t s) {
   if (lds <= 80 * 1024) return launch_nt<S, TH, TW, EXPAND, 512>(a, lds, 512, s);
   return launch_nt<S, TH, TW, EXPAND, 1024>(a, lds, 256, s);
 }
+
+const int conv_mb_debug = [] {      // YOLO_MBCONV_DEBUG bit 1: never halve the tile (tuning only)
+  const char* e = getenv("YOLO_MBCONV_DEBUG");
+  return e ? atoi(e) : 0;
+}();
 
 }  // namespace
 
@@ -324,6 +334,13 @@ extern "C" int yolo_mbconv_fwd(const void* x, const void* w_exp, const float* b_
   a.dstride = yolo_mbconv_dstride(a.ce);
   a.tiles_x = a.tiles_y = a.n_tiles = 0;
   hipStream_t st = (hipStream_t)s;
-  if (d.stride == 1) return d.has_expand ? launch<1, 8, 8, true>(a, st) : launch<1, 8, 8, false>(a, st);
+  // tile: 8x8 outputs (4x8 at stride 2).  192 hidden channels at stride 1: 4x8, which lets two 512-thread workgroups
+  // share a CU instead of one of 1024 threads (-10 %; with 144 hidden channels and at stride 2 the larger halo
+  // share of a half tile costs more than the overlap gains: measured, YOLO_MBCONV_DEBUG bit 1 = always the full tile)
+  if (d.stride == 1) {
+    if (!d.has_expand) return launch<1, 8, 8, false>(a, st);
+    if (a.ce >= 192 && !(conv_mb_debug & 1) && lds_bytes<1, 4, 8, true>(a) <= 80 * 1024) return launch<1, 4, 8, true>(a, st);
+    return launch<1, 8, 8, true>(a, st);
+  }
   return d.has_expand ? launch<2, 4, 8, true>(a, st) : launch<2, 4, 8, false>(a, st);
 }
