@@ -424,19 +424,26 @@ def test_spp_exact(h, w):
     assert torch.equal(got, want)
 
 
-def test_dwconv():
+@pytest.mark.parametrize("n,c,h,w", [(2, 32, 15, 18), (1, 384, 26, 26), (2, 960, 13, 13), (1, 48, 7, 33), (1, 8, 1, 1)])
+def test_dwconv(n, c, h, w):
+    """yolo_dwconv3x3_fwd (strip kernel: 8 output rows per thread, sliding input rows) against fp32 torch on the same
+    bf16 input, strides 1 and 2, channel-offset views on both sides, heights that are not a multiple of the strip."""
     from pytorch_yolo_amd import kernels as K
     from pytorch_yolo_amd._lib import ACT_RELU6
+    g = torch.Generator().manual_seed(c + h)
     for stride in (1, 2):
-        x = torch.randn(2, 32, 15, 18)
-        wt = torch.randn(32, 1, 3, 3) * 0.3
-        b = torch.randn(32) * 0.1
-        ho, wo = (15 - 1) // stride + 1, (18 - 1) // stride + 1
-        y = torch.zeros(2, ho, wo, 32, dtype=torch.bfloat16, device=DEV)
-        K.dwconv3x3(_nhwc(x), wt.reshape(32, 9).t().contiguous().to(DEV), b.to(DEV), y, n=2, h=15, w=18, c=32,
-                    in_view=(32, 0), out_view=(32, 0), stride=stride, act=ACT_RELU6)
-        ref = F.relu6(F.conv2d(_bf16r(x), wt, b, stride=stride, padding=1, groups=32))
-        torch.testing.assert_close(_nchw(y), ref, rtol=1e-2, atol=1e-2)
+        x = torch.randn(n, c, h, w, generator=g)
+        wt = torch.randn(c, 1, 3, 3, generator=g) * 0.3
+        b = torch.randn(c, generator=g) * 0.1
+        ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+        xin = torch.zeros(n, h, w, c + 16, dtype=torch.bfloat16, device=DEV)
+        xin[..., 8:8 + c] = _nhwc(x)
+        y = torch.full((n, ho, wo, c + 8), -77.0, dtype=torch.bfloat16, device=DEV)
+        K.dwconv3x3(xin, wt.reshape(c, 9).t().contiguous().to(DEV), b.to(DEV), y, n=n, h=h, w=w, c=c,
+                    in_view=(c + 16, 8), out_view=(c + 8, 8), stride=stride, act=ACT_RELU6)
+        ref = F.relu6(F.conv2d(_bf16r(x), wt, b, stride=stride, padding=1, groups=c))
+        torch.testing.assert_close(_nchw(y[..., 8:]), ref, rtol=1e-2, atol=1e-2)
+        assert torch.all(y[..., :8] == -77.0)
 
 
 @pytest.mark.parametrize("nc,ny,nx,img", [(80, 13, 13, 416), (3, 4, 6, 96), (1, 5, 5, 160), (80, 80, 80, 640)])
