@@ -616,8 +616,11 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
   if (d.cout <= 32) return fast32 ? YOLO_CFG(256, 32, 4, 1, 32, 2, true) : YOLO_CFG(256, 32, 4, 1, 32, 2, false);
   // few pixels, few output channels, long K (MobileNetV2-tiny head: 3x3 1280 -> 64 on 13x13): 256-row tiles leave most
   // CUs idle, 64x64 tiles quadruple the workgroup count
-  if (d.cout == 64 && fast64 && epi && (M + 255) / 256 < 128 && conv_variant_override < 0 && !(conv_debug_flags & 2048))
-    return launch_cfg<64, 64, 2, 2, 64, 2, true, true, true>(a, s);
+  // ... and with one small workgroup per CU nothing hides the LDS-DMA latency of a two-stage ring: four stages
+  if (d.cout == 64 && fast64 && epi && (M + 255) / 256 < 128 && conv_variant_override < 0 && !(conv_debug_flags & 2048)) {
+    if (conv_debug_flags & 4194304) return launch_cfg<64, 64, 2, 2, 64, 2, true, true, true>(a, s);
+    return launch_cfg<64, 64, 2, 2, 64, 4, true, true, true>(a, s);
+  }
   if (d.cout <= 64) return fast32 ? YOLO_CFG(256, 64, 4, 1, 32, 2, true) : YOLO_CFG(256, 64, 4, 1, 32, 2, false);
   if (!fast64) return fast32 ? YOLO_CFG(128, 128, 2, 2, 32, 3, true) : YOLO_CFG(128, 128, 2, 2, 32, 3, false);
   // 256x256 (8 waves, one block per CU) halves the operand traffic per FLOP but needs enough tiles to fill
