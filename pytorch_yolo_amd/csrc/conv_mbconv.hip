@@ -32,6 +32,7 @@ struct MbArgs {
   const float* bp;      // [cop]
   int n, h, w, ho, wo, cin, in_ct, in_co, ce, cout, cop, out_ct, out_co, has_res;
   int tiles_x, tiles_y, n_tiles, dstride;
+  int debug;            // YOLO_MBCONV_DEBUG (timing only, results wrong): 2 no expand stage, 4 no depthwise stage, 8 no projection stage, 16 no x loads
 };
 
 constexpr int kXStride = 96;      // bytes per pixel row of the x tile / per row of W_expand: 32 bf16 + pad; rows 24 banks
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void mb
   // 8 bytes apart spreads them over the banks); without an expand conv the rows take 16-byte tile loads
   const int ce = a.ce, estride = ce * 2 + (EXPAND ? 8 : 0), dstride = a.dstride;
   // LDS map: [X tile HPP x 96 B (EXPAND only)] [E: HPP x estride] [D: P x dstride] [W_expand: ce x 96 B] [W_proj: cop x dstride]
-  // [b_expand f32 ce] [b_proj f32 cop]
+  // [b_expand f32 ce] [b_proj f32 cop] [-1e30 f32 ce]
   char* const lx = smem;
   char* const le = lx + (EXPAND ? HPP * kXStride : 0);
   char* const ld = le + HPP * estride;
@@ -64,13 +65,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void mb
   char* const lwp = lwe + (EXPAND ? ce * kXStride : 0);
   float* const lbe = reinterpret_cast<float*>(lwp + a.cop * dstride);
   float* const lbp = lbe + ce;
+  float* const lbad = lbp + a.cop;                       // [ce] x -1e30 (EXPAND only)
 
   // ---- once per workgroup: weights -> LDS, zero the K padding of the x tile
   if (EXPAND) {
     for (int i = tid; i < ce * (kXStride / 16); i += nt)
       reinterpret_cast<uint4*>(lwe)[i] = reinterpret_cast<const uint4*>(a.we)[i];
     for (int i = tid; i < HPP * (kXStride / 16); i += nt) reinterpret_cast<uint4*>(lx)[i] = make_uint4(0, 0, 0, 0);
-    for (int i = tid; i < ce; i += nt) lbe[i] = a.be[i];
+    for (int i = tid; i < ce; i += nt) lbe[i] = a.be[i], lbad[i] = -1e30f;
   } else {
     for (int i = tid; i < HPP * estride / 16; i += nt) reinterpret_cast<uint4*>(le)[i] = make_uint4(0, 0, 0, 0);
   }
@@ -133,44 +135,43 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void mb
     const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
     // ---- A: this tile's x halo (fetched during the previous tile) -> LDS; next tile's loads go out
     stash();
-    if (tile + (int)gridDim.x < a.n_tiles) fetch(tile + gridDim.x);
+    if (tile + (int)gridDim.x < a.n_tiles && !(a.debug & 16)) fetch(tile + gridDim.x);
     __syncthreads();
     // ---- B: E = relu6(X We^T + be), 0 outside the image
-    if (EXPAND) {
-      // two 16x16 tiles per iteration: their LDS reads, MFMAs and epilogues overlap
-      const int nct = ce / 16, ntl = (HPP / 16) * nct;
-      for (int t = wave; t < ntl; t += 2 * nw) {
-        const bool two = t + nw < ntl;
-        const int tt[2] = {t, two ? t + nw : t};
-        bf16x8 wf[2], xf[2];
-        int rt[2], ct[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          rt[u] = tt[u] / nct, ct[u] = tt[u] - rt[u] * nct;
-          wf[u] = *reinterpret_cast<const bf16x8*>(lwe + (ct[u] * 16 + c16) * kXStride + q * 16);
-          xf[u] = *reinterpret_cast<const bf16x8*>(lx + (rt[u] * 16 + c16) * kXStride + q * 16);
-        }
-        f32x4 acc[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {        // the bias is the accumulator's start value
-          acc[u] = *reinterpret_cast<const f32x4*>(lbe + ct[u] * 16 + q * 4);
-          acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u], xf[u], acc[u], 0, 0, 0);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int pix = rt[u] * 16 + c16, c0 = ct[u] * 16 + q * 4;      // lane: pixel c16, channels c0..c0+3
+    if (EXPAND && !(a.debug & 2)) {
+      // A wave takes a contiguous run of 16x16 tiles in pixel-row-major order, so consecutive tiles share their 16
+      // halo pixels: the pixel fragment, the in-image test and the E row address are set up once per pixel row
+      // (a wave-uniform branch) and a tile costs ~13 instructions.  Out-of-image lanes take their "bias" from a
+      // table of -1e30, which the ReLU6 clamp turns into the zero the depthwise conv must see there.
+      const int nct = ce / 16, ntl = (HPP / 16) * nct, per = (ntl + nw - 1) / nw;
+      const int t_hi = min(ntl, (wave + 1) * per);
+      int cur_rt = -1;
+      bf16x8 xf = {};
+      char* erow = nullptr;
+      const float* bsrc = lbe;
+      for (int t = wave * per; t < t_hi; ++t) {
+        const int rt = t / nct, ct = t - rt * nct;
+        if (rt != cur_rt) {
+          cur_rt = rt;
+          const int pix = rt * 16 + c16;
           const int iy = iy0 + pix / IW, ix = ix0 + pix % IW;
           const bool in = pix < HP && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;
-          bf16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(in ? relu6(acc[u][e]) : 0.f);
-          if (pix < HP && (u == 0 || two)) *reinterpret_cast<bf16x4*>(le + pix * estride + c0 * 2) = o;
+          bsrc = (in ? lbe : lbad) + q * 4;
+          erow = pix < HP ? le + pix * estride + q * 8 : nullptr;
+          xf = *reinterpret_cast<const bf16x8*>(lx + pix * kXStride + q * 16);
         }
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(lwe + (ct * 16 + c16) * kXStride + q * 16);
+        f32x4 acc = *reinterpret_cast<const f32x4*>(bsrc + ct * 16);     // the bias is the accumulator's start value
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc, 0, 0, 0);
+        bf16x4 o;                                                          // lane: pixel c16, channels ct*16 + q*4 ..+3
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)relu6(acc[e]);
+        if (erow) *reinterpret_cast<bf16x4*>(erow + ct * 32) = o;
       }
-      __syncthreads();
     }
+    if (EXPAND) __syncthreads();
     // ---- C: D = relu6(dw3x3(E) + bd)
-    if (dw_on) {
+    if (dw_on && !(a.debug & 4)) {
       for (int p = grp; p < P; p += 2 * groups) {       // two pixels per iteration
         const bool two = p + groups < P;
         const int pp[2] = {p, two ? p + groups : p};
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void mb
     }
     __syncthreads();
     // ---- D: y = D Wp^T + bp (+ x)
-    {
+    if (!(a.debug & 8)) {
       const int nct = a.cop / 16, ntl = (P / 16) * nct, ksteps = ce / 32;
       for (int t = wave; t < ntl; t += nw) {
         const int rt = t / nct, ct = t - rt * nct;
@@ -258,7 +259,7 @@ template <int S, int TH, int TW, bool EXPAND>
 size_t lds_bytes(const MbArgs& a) {
   constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3, HP = IH * IW, HPP = (HP + 15) / 16 * 16, P = TH * TW;
   return (size_t)(EXPAND ? HPP * kXStride : 0) + (size_t)HPP * (a.ce * 2 + (EXPAND ? 8 : 0)) + (size_t)P * a.dstride +
-         (size_t)(EXPAND ? a.ce * kXStride : 0) + (size_t)a.cop * a.dstride + (size_t)(a.ce + a.cop) * 4;
+         (size_t)(EXPAND ? a.ce * kXStride : 0) + (size_t)a.cop * a.dstride + (size_t)(a.ce + a.cop + (EXPAND ? a.ce : 0)) * 4;
 }
 
 template <int S, int TH, int TW, bool EXPAND>
@@ -333,13 +334,14 @@ extern "C" int yolo_mbconv_fwd(const void* x, const void* w_exp, const float* b_
   a.has_res = d.has_res;
   a.dstride = yolo_mbconv_dstride(a.ce);
   a.tiles_x = a.tiles_y = a.n_tiles = 0;
+  a.debug = conv_mb_debug;
   hipStream_t st = (hipStream_t)s;
   // tile: 8x8 outputs (4x8 at stride 2).  192 hidden channels at stride 1: 4x8, which lets two 512-thread workgroups
   // share a CU instead of one of 1024 threads (-10 %; with 144 hidden channels and at stride 2 the larger halo
   // share of a half tile costs more than the overlap gains: measured, YOLO_MBCONV_DEBUG bit 1 = always the full tile)
   if (d.stride == 1) {
     if (!d.has_expand) return launch<1, 8, 8, false>(a, st);
-    if (a.ce >= 192 && !(conv_mb_debug & 1) && lds_bytes<1, 4, 8, true>(a) <= 80 * 1024) return launch<1, 4, 8, true>(a, st);
+    if ((a.ce >= 192 || (conv_mb_debug & 32)) && !(conv_mb_debug & 1) && lds_bytes<1, 4, 8, true>(a) <= 80 * 1024) return launch<1, 4, 8, true>(a, st);
     return launch<1, 8, 8, true>(a, st);
   }
   return d.has_expand ? launch<2, 4, 8, true>(a, st) : launch<2, 4, 8, false>(a, st);
