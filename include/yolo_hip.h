@@ -92,6 +92,14 @@ YOLO_API int yolo_conv1_pool_nchw_f32_fwd(const float* x_nchw, int cin_real, con
 YOLO_API int yolo_pack_conv_weight_f32(const float* w_oihw, int cout, int cin_w, int ksize, int cin,
                               int cout_pad, int kpad, uint16_t* out);
 
+/* ---- 3x3 / stride 1 / pad 1 ConvBlock with 16 or 32 input channels and 32 or 64 output channels, optionally followed by
+ *  MaxPool2d(2, 2): the second and third ConvPoolBlock of YOLOv3-tiny (models/yolo_base.py:69-80, yolov3_tiny.py:26-29)
+ *  in ONE launch; with pool != 0 y is the bf16 NHWC view of the POOLED map [n, h/2, w/2, ...] and the full-resolution
+ *  conv output is never written.  x: bf16 NHWC view, w_packed / bias as for yolo_conv2d_fwd, d describes the conv. */
+YOLO_API int yolo_conv3x3_pool_supported(int cin, int cout);
+YOLO_API int yolo_conv3x3_pool_fwd(const void* x, const void* w_packed, const float* bias, void* y, const YoloConvDesc* d,
+                                   int pool, yolo_stream_t s);
+
 /* ---- depthwise 3x3 conv + bias + act (MobileNetV2 inverted residual; torchvision, see
  *      models/yolov3_tiny_mobilenet.py:11-34).  w: f32 [9][c] tap-major, bias f32 [c]. */
 YOLO_API int yolo_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int n, int h, int w_,
@@ -197,7 +205,8 @@ YOLO_API int yolo_letterbox_u8_fwd(const uint8_t* src, int h, int w, int c, int 
 
 /* ---- batched launcher: run a recorded list of ops with one FFI crossing (host overhead only). */
 enum { YOLO_OP_CONV = 1, YOLO_OP_MAXPOOL = 2, YOLO_OP_SPP = 3, YOLO_OP_DWCONV = 4, YOLO_OP_CONV1_NCHW = 5,
-       YOLO_OP_RESUNIT = 6, YOLO_OP_STEM = 7, YOLO_OP_HEAD_DECODE = 8, YOLO_OP_CONV1_POOL = 9, YOLO_OP_MBCONV = 10 };
+       YOLO_OP_RESUNIT = 6, YOLO_OP_STEM = 7, YOLO_OP_HEAD_DECODE = 8, YOLO_OP_CONV1_POOL = 9, YOLO_OP_MBCONV = 10,
+       YOLO_OP_CONV_POOL = 11 /* yolo_conv3x3_pool_fwd with pool = 1: x = bf16 NHWC, y = the pooled map */ };
 typedef struct YoloOp {
   int32_t kind, _pad;
   const void* x; const void* w; const float* bias; const void* residual; void* y; void* y_aux;

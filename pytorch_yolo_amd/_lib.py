@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("YOLO_HIP_LIB") or os.path.join(_HERE, "csrc", "libyol
 ACT_NONE, ACT_LEAKY01, ACT_RELU6 = 0, 1, 2
 DT_BF16, DT_F32 = 0, 1
 OP_CONV, OP_MAXPOOL, OP_SPP, OP_DWCONV, OP_CONV1_NCHW, OP_RESUNIT, OP_STEM, OP_HEAD_DECODE, OP_CONV1_POOL = 1, 2, 3, 4, 5, 6, 7, 8, 9
-OP_MBCONV = 10
+OP_MBCONV, OP_CONV_POOL = 10, 11
 
 
 class YoloConvDesc(C.Structure):
@@ -59,6 +59,8 @@ SIGNATURES = {
                                 C.POINTER(YoloConvDesc), C.c_void_p]),
     "yolo_resunit_supported": (C.c_int, [C.c_int] * 3),
     "yolo_resunit_fwd": (C.c_int, [C.c_void_p] * 7 + [C.POINTER(YoloConvDesc), C.c_int, C.c_int, C.c_void_p]),
+    "yolo_conv3x3_pool_supported": (C.c_int, [C.c_int] * 2),
+    "yolo_conv3x3_pool_fwd": (C.c_int, [C.c_void_p] * 4 + [C.POINTER(YoloConvDesc), C.c_int, C.c_void_p]),
     "yolo_mbconv_dstride": (C.c_int, [C.c_int]),
     "yolo_mbconv_supported": (C.c_int, [C.c_int] * 4),
     "yolo_mbconv_fwd": (C.c_int, [C.c_void_p] * 8 + [C.POINTER(YoloMbconvDesc), C.c_void_p]),

@@ -22,6 +22,7 @@ SOURCES = {
     "conv_resunit.hip": [],
     "conv_stem.hip": [],
     "conv_mbconv.hip": [],
+    "conv_small.hip": [],
     "pointwise.hip": [],
     "preprocess.hip": ["-ffp-contract=off"],
     "nms.hip": ["-ffp-contract=off"],

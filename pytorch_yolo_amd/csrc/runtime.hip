@@ -53,6 +53,9 @@ extern "C" int yolo_run_ops(const YoloOp* ops, int n_ops, yolo_stream_t s) {
         rc = yolo_head_decode_fwd(o.x, o.w, o.bias, &d, o.head_anchors_px, o.head_na, o.head_nc, o.head_stride_px, (float*)o.y,
                                   o.io_rows_total, o.io_row_offset, (float*)o.y_aux, s);
         break;
+      case YOLO_OP_CONV_POOL:
+        rc = yolo_conv3x3_pool_fwd(o.x, o.w, o.bias, o.y, &d, 1, s);
+        break;
       case YOLO_OP_MBCONV: {
         YoloMbconvDesc m;
         m.n = d.n, m.h = d.h, m.w = d.w, m.cin = d.cin, m.in_c_total = d.in_c_total, m.in_c_offset = d.in_c_offset;

@@ -28,7 +28,7 @@ import torch
 
 from . import kernels as K
 from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU6, DT_BF16, DT_F32, OP_CONV, OP_CONV1_NCHW, OP_DWCONV,
-                   OP_CONV1_POOL, OP_MBCONV, OP_HEAD_DECODE, OP_MAXPOOL, OP_RESUNIT, OP_SPP, OP_STEM, YoloOp)
+                   OP_CONV1_POOL, OP_CONV_POOL, OP_MBCONV, OP_HEAD_DECODE, OP_MAXPOOL, OP_RESUNIT, OP_SPP, OP_STEM, YoloOp)
 
 # which residual-unit widths run as ONE launch (bit mask of C: 64 | 128 | 256); see DESIGN.md §3.1d for the
 # measurements behind the default.  YOLO_FUSE_RESUNIT overrides it (tuning only).
@@ -251,6 +251,24 @@ class Plan:
                     dwn.attrs["fused_away"] = True
                     if has_exp:
                         ex.attrs["fused_away"] = True
+        # 2d. ConvPoolBlocks with few input channels (YOLOv3-tiny's second and third: 16 -> 32, 32 -> 64): conv + MaxPool2d(2, 2)
+        #     in one launch (yolo_conv3x3_pool_fwd), the full-resolution conv output is never written
+        if os.environ.get("YOLO_FUSE_POOL", "1") == "1":
+            for nd in nodes:
+                if (nd.kind != "conv" or nd.attrs["has_res"] or len(nd.outs) != 1 or "up_into" in nd.attrs or nd.attrs["stride"] != 1
+                        or nd.attrs.get("fused_away") or nd.srcs[0] is self.rec.input):
+                    continue
+                w, _ = nd.attrs["weight"]
+                mid = nd.outs[0]
+                if (w.shape[2] != 3 or mid.f32 or mid.buf is not None or len(mid.consumers) != 1 or mid.consumers[0].kind != "pool"
+                        or not K.conv3x3_pool_supported(w.shape[1], w.shape[0]) or mid.h % 2 or mid.w % 2):
+                    continue
+                ndp = mid.consumers[0]
+                if (ndp.attrs["size"], ndp.attrs["stride"], ndp.attrs["pad"], ndp.attrs["dil"]) != (2, 2, 0, 1):
+                    continue
+                nd.attrs["pool_into"] = ndp.outs[0]
+                nd.attrs["small_pool"] = True
+                ndp.attrs["fused_away"] = True
         # 3. residual adds are written in place of the residual input when it is dead afterwards
         for nd in nodes:
             if nd.kind == "conv" and nd.attrs["has_res"] and "fuse_pre" not in nd.attrs and "mb_pre" not in nd.attrs:
@@ -274,6 +292,11 @@ class Plan:
             if nd.attrs.get("fused_away") or nd.attrs.get("head_fused"):
                 continue
             for o in nd.outs:
+                if nd.kind == "conv" and nd.attrs.get("small_pool"):
+                    pooled = nd.attrs["pool_into"]         # the full-resolution map is never materialised, the pooled one is
+                    if pooled.buf is None:
+                        pooled.buf, pooled.c_offset = self._new_buf(pooled), 0
+                    continue
                 if o.buf is None and not (nd.kind == "conv" and "up_into" in nd.attrs and o.slot == 0):
                     if nd.kind == "conv" and nd.attrs.get("alias_res") and o.slot == 0:
                         continue
@@ -458,7 +481,8 @@ class Plan:
                 wp, bp, kpad, cout_pad = K.pack_conv_weight(w, b, x.c)
                 wp, bp = self._dev(wp), self._dev(bp)
                 up = nd.attrs.get("up_into")
-                dst = up if up is not None else y
+                pooled = nd.attrs.get("pool_into")         # conv + MaxPool2d(2, 2) in one launch: the op writes the pooled map
+                dst = pooled if pooled is not None else (up if up is not None else y)
                 res = nd.srcs[1] if nd.attrs["has_res"] else None
                 aux = nd.outs[1] if len(nd.outs) > 1 else None
                 d = K.conv_desc(n=x.n, h=x.h, w=x.w, cin=x.c, in_c_total=x.buf.c_total, in_c_offset=x.c_offset,
@@ -470,11 +494,11 @@ class Plan:
                                 aux=(aux.buf.c_total, aux.c_offset) if aux is not None else (0, 0))
                 op = YoloOp()
                 fused_first = self.fused_input and x is self.rec.input
-                pooled = nd.attrs.get("pool_into")
-                if pooled is not None:                     # conv1 + MaxPool2d(2, 2): the op writes the pooled map
-                    d.out_c_total, d.out_c_offset = pooled.buf.c_total, pooled.c_offset
-                    dst = pooled
-                op.kind = (OP_CONV1_POOL if pooled is not None else OP_CONV1_NCHW) if fused_first else OP_CONV
+                if fused_first:
+                    op.kind = OP_CONV1_POOL if pooled is not None else OP_CONV1_NCHW
+                else:
+                    op.kind = OP_CONV_POOL if nd.attrs.get("small_pool") else OP_CONV
+                    assert pooled is None or op.kind == OP_CONV_POOL
                 if fused_first:
                     d.res_c_total = self.rec.c_in          # real input channels (x pointer is patched per call)
                 op.x = None if fused_first else x.buf.tensor.data_ptr()
@@ -579,7 +603,7 @@ class Plan:
         for i in range(self.n_ops):
             op = self.op_array[i]
             d = op.conv
-            if op.kind in (OP_CONV, OP_CONV1_NCHW, OP_CONV1_POOL, OP_HEAD_DECODE):
+            if op.kind in (OP_CONV, OP_CONV1_NCHW, OP_CONV1_POOL, OP_CONV_POOL, OP_HEAD_DECODE):
                 cin = self.rec.c_in if first else d.cin      # the first layer's 3 -> 8 channel pad is not work
                 first = False
                 total += 2.0 * d.n * d.ho * d.wo * d.cout * d.ksize * d.ksize * cin

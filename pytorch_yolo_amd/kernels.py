@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU6, DT_BF16, DT_F32, YoloConvDesc, YoloMbconvDesc,
                    check, load)
 
-__all__ = ["stream_ptr", "pack_input", "conv2d", "stem", "resunit", "resunit_supported", "maxpool", "spp", "dwconv3x3", "mbconv", "mbconv_supported", "pack_mbconv", "decode", "head_decode", "head_decode_supported",
+__all__ = ["stream_ptr", "pack_input", "conv2d", "stem", "resunit", "resunit_supported", "maxpool", "spp", "dwconv3x3", "mbconv", "mbconv_supported", "pack_mbconv", "conv3x3_pool", "conv3x3_pool_supported", "decode", "head_decode", "head_decode_supported",
            "nms_merge", "pack_conv_weight", "roundup", "run_ops"]
 
 
@@ -123,6 +123,19 @@ def dwconv3x3(x, w9c, bias, y, *, n, h, w, c, in_view, out_view, stride, act):
     ho, wo = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
     check(load().yolo_dwconv3x3_fwd(_ptr(x), _ptr(w9c), _ptr(bias), _ptr(y), n, h, w, c, in_view[0], in_view[1],
                                     ho, wo, out_view[0], out_view[1], stride, act, stream_ptr()), "dwconv3x3")
+    return y
+
+
+def conv3x3_pool_supported(cin: int, cout: int) -> bool:
+    return bool(load().yolo_conv3x3_pool_supported(cin, cout))
+
+
+def conv3x3_pool(x, w_packed, bias, y, desc: YoloConvDesc, pool: bool = True):
+    """3x3 / s1 ConvBlock with 16 | 32 input and 32 | 64 output channels (+ MaxPool2d(2, 2) when ``pool``): y is the
+    pooled map then (yolo_conv3x3_pool_fwd)."""
+    _need_cuda(x, w_packed, bias, y)
+    check(load().yolo_conv3x3_pool_fwd(_ptr(x), _ptr(w_packed), _ptr(bias), _ptr(y), C.byref(desc), 1 if pool else 0,
+                                       stream_ptr()), "conv3x3_pool")
     return y
 
 

@@ -424,6 +424,49 @@ def test_spp_exact(h, w):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout,pool", [(2, 52, 52, 16, 32, True), (1, 40, 72, 32, 64, True), (2, 26, 38, 16, 64, True),
+                                                 (1, 208, 208, 16, 32, True), (2, 30, 22, 32, 32, False), (1, 17, 33, 16, 32, True)])
+def test_small_cin_conv_with_maxpool(n, h, w, cin, cout, pool):
+    """yolo_conv3x3_pool_fwd (3x3 ConvBlock with 16 / 32 input channels + MaxPool2d(2, 2) in one launch) against fp32
+    torch on the same bf16 operands, and against the two-launch path (yolo_conv2d_fwd + yolo_maxpool_fwd): the pooled
+    values are maxima of the same bf16-rounded conv outputs, so they agree up to fp32 summation order.  Partial tiles,
+    odd sizes (floor pooling), several tiles per workgroup and channel-offset views are exercised."""
+    from pytorch_yolo_amd import kernels as K
+    from pytorch_yolo_amd._lib import ACT_LEAKY01
+    assert K.conv3x3_pool_supported(cin, cout)
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    in_ct, in_co, out_ct, out_co = cin + 16, 8, cout + 8, 8
+    xin = torch.zeros(n, h, w, in_ct, dtype=torch.bfloat16, device=DEV)
+    xin[..., in_co:in_co + cin] = _nhwc(x)
+    ho, wo = (h // 2, w // 2) if pool else (h, w)
+    y = torch.full((n, ho, wo, out_ct), -77.0, dtype=torch.bfloat16, device=DEV)
+    wp, bp, kpad, cpad = K.pack_conv_weight(wt, b, cin)
+    d = K.conv_desc(n=n, h=h, w=w, cin=cin, in_c_total=in_ct, in_c_offset=in_co, cout=cout, out_c_total=out_ct,
+                    out_c_offset=out_co, ksize=3, stride=1, act=ACT_LEAKY01, kpad=kpad, cout_pad=cpad)
+    K.conv3x3_pool(xin, wp.to(DEV), bp.to(DEV), y, d, pool=pool)
+    torch.cuda.synchronize()
+    conv = _bf16r(F.leaky_relu(F.conv2d(_bf16r(x), _bf16r(wt), b, padding=1), 0.1))
+    ref = F.max_pool2d(conv, 2, 2) if pool else conv
+    torch.testing.assert_close(_nchw(y[..., out_co:]), ref, rtol=1e-2, atol=2e-2)
+    assert torch.all(y[..., :out_co] == -77.0)
+    # two-launch path
+    full = torch.empty(n, h, w, cout, dtype=torch.bfloat16, device=DEV)
+    d2 = K.conv_desc(n=n, h=h, w=w, cin=cin, in_c_total=in_ct, in_c_offset=in_co, cout=cout, out_c_total=cout, out_c_offset=0,
+                     ksize=3, stride=1, act=ACT_LEAKY01, kpad=kpad, cout_pad=cpad)
+    K.conv2d(xin, wp.to(DEV), bp.to(DEV), full, d2)
+    if pool:
+        y2 = torch.empty(n, ho, wo, cout, dtype=torch.bfloat16, device=DEV)
+        K.maxpool(full, y2, n=n, h=h, w=w, c=cout, in_view=(cout, 0), out_view=(cout, 0), ksize=2, stride=2, pad=0, dilation=1)
+    else:
+        y2 = full
+    torch.cuda.synchronize()
+    diff = (y[..., out_co:].float() - y2.float()).abs()
+    assert float(diff.max()) <= 0.07 and float((diff > 0).float().mean()) < 0.25, (float(diff.max()), float((diff > 0).float().mean()))
+
+
 @pytest.mark.parametrize("n,c,h,w", [(2, 32, 15, 18), (1, 384, 26, 26), (2, 960, 13, 13), (1, 48, 7, 33), (1, 8, 1, 1)])
 def test_dwconv(n, c, h, w):
     """yolo_dwconv3x3_fwd (strip kernel: 8 output rows per thread, sliding input rows) against fp32 torch on the same

@@ -13,7 +13,7 @@ import torch
 import _cases as C
 from pytorch_yolo_amd import YOLOv3SPP, YOLOv3Tiny, YOLOv3TinyMobile, _lib, engine
 from pytorch_yolo_amd import kernels as K
-from pytorch_yolo_amd._lib import OP_MBCONV, OP_CONV, OP_CONV1_NCHW, OP_CONV1_POOL, OP_HEAD_DECODE, OP_RESUNIT, OP_STEM, OP_DWCONV, OP_MAXPOOL, OP_SPP
+from pytorch_yolo_amd._lib import OP_MBCONV, OP_CONV_POOL, OP_CONV, OP_CONV1_NCHW, OP_CONV1_POOL, OP_HEAD_DECODE, OP_RESUNIT, OP_STEM, OP_DWCONV, OP_MAXPOOL, OP_SPP
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -143,7 +143,10 @@ def test_planner_tiny_and_mobile():
     # the first ConvPoolBlock (3 -> 16, MaxPool2d(2, 2)) reads the NCHW f32 batch and writes the pooled map in ONE launch
     ops = _ops(plan)
     assert ops[0].kind == OP_CONV1_POOL and plan.fused_input and (ops[0].conv.cout, ops[0].conv.h, ops[0].conv.out_c_total) == (16, 416, 16)
-    assert kinds.count(OP_CONV) == 10 and kinds.count(OP_HEAD_DECODE) == 2 and kinds.count(OP_MAXPOOL) == 5
+    # the second and third ConvPoolBlock (16 -> 32 @208, 32 -> 64 @104) are one launch each too (yolo_conv3x3_pool_fwd)
+    cp = [o for o in ops if o.kind == OP_CONV_POOL]
+    assert [(o.conv.cin, o.conv.cout, o.conv.h, o.conv.out_c_total) for o in cp] == [(16, 32, 208, 32), (32, 64, 104, 64)]
+    assert kinds.count(OP_CONV) == 8 and kinds.count(OP_HEAD_DECODE) == 2 and kinds.count(OP_MAXPOOL) == 3
     pools = [o.conv for o in _ops(plan) if o.kind == OP_MAXPOOL]
     assert (pools[-1].ksize, pools[-1].stride, pools[-1].pad, pools[-1].upsample2x) == (2, 1, 1, 2)   # dilated special
     # route1 is produced straight into the concat buffer [route1(256) | upsampled(128)]

@@ -66,7 +66,7 @@ def main():
             tot_fl += fl
             by = d.n * d.h * d.w * 3 * 4 + M * 64 * 2
             print(f"{i:3d} {'stem':7} {M:9d} {64:5d} {288:5d} 3 2 {ms:8.4f} {fl / ms / 1e9:8.1f} {by / ms / 1e6:7.0f}  conv1+s2")
-        elif op.kind in (OP_CONV, OP_CONV1_NCHW, OP_HEAD_DECODE, 9):
+        elif op.kind in (OP_CONV, OP_CONV1_NCHW, OP_HEAD_DECODE, 9, 11):
             M, N, Kd = d.n * d.ho * d.wo, d.cout, d.ksize * d.ksize * d.cin
             fl = 2.0 * M * N * Kd
             by = d.n * d.h * d.w * d.cin * 2 + M * N * (4 if d.out_dtype else 2) * (4 if d.upsample2x else 1) + N * Kd * 2
