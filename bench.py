@@ -22,7 +22,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from pytorch_yolo_amd import YOLOv3SPP, YOLOv3Tiny, YOLOv3TinyMobile          # noqa: E402
+from pytorch_yolo_amd import YOLOv3SPP, YOLOv3Tiny, YOLOv3TinyMobile, YOLOv3TinySqueeze          # noqa: E402
 from pytorch_yolo_amd.distributed import PipelinedGather                    # noqa: E402
 from pytorch_yolo_amd.utils.synthetic import synth_images, synth_state_dict  # noqa: E402
 from pytorch_yolo_amd.utils.utils import nms_capacity, nms_raw               # noqa: E402
@@ -40,6 +40,8 @@ WORKLOADS = {
                  name="YOLOv3-tiny Darknet-15 416x416 bs=32/GPU detect()"),
     "mobile": dict(cls=YOLOv3TinyMobile, kw=dict(), hw=416, bs=64,
                    name="YOLOv3-tiny MobileNetV2 416x416 bs=64/GPU detect()"),
+    "squeeze": dict(cls=YOLOv3TinySqueeze, kw=dict(), hw=416, bs=32,
+                    name="YOLOv3-tiny SqueezeNet 1.1 416x416 bs=32/GPU detect()"),
 }
 CONF_THRES, NMS_THRES = 0.1, 0.5
 
@@ -66,12 +68,14 @@ def cpu_baseline(workload: str, seconds_budget: float = 20.0):
     import numpy as np
     from oracle import models as om
     from oracle import nms as onms
-    if workload != "spp":
-        fwd, anchors, hw = om.tiny_forward, om.TINY_ANCHORS, 416
-        tmpl = YOLOv3Tiny().state_dict()
-    else:
+    if workload == "spp":
         fwd, anchors, hw = om.spp_forward, om.SPP_ANCHORS, 640
         tmpl = YOLOv3SPP(anchors=SPP_ANCHORS).state_dict()
+    else:
+        fwd, cls = {"tiny": (om.tiny_forward, YOLOv3Tiny), "mobile": (om.tiny_mobile_forward, YOLOv3TinyMobile),
+                    "squeeze": (om.tiny_squeeze_forward, YOLOv3TinySqueeze)}[workload]
+        anchors, hw = om.TINY_ANCHORS, 416
+        tmpl = cls().state_dict()
     cores = host_cores()
     torch.set_num_threads(cores)
     sd = synth_state_dict(tmpl, 1234, n_class=80)

@@ -34,7 +34,7 @@ typedef void* yolo_stream_t; /* hipStream_t */
 #endif
 
 enum { YOLO_E_ARG = -1, YOLO_E_UNSUPPORTED = -2, YOLO_E_WORKSPACE = -3 };
-enum { YOLO_ACT_NONE = 0, YOLO_ACT_LEAKY01 = 1, YOLO_ACT_RELU6 = 2 };
+enum { YOLO_ACT_NONE = 0, YOLO_ACT_LEAKY01 = 1, YOLO_ACT_RELU6 = 2, YOLO_ACT_RELU = 3 };
 enum { YOLO_DT_BF16 = 0, YOLO_DT_F32 = 1 };
 
 YOLO_API const char* yolo_last_error(void);

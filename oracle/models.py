@@ -124,6 +124,21 @@ def tiny_mobile_forward(sd, x, anchors=TINY_ANCHORS, n_class=80):
     return tiny_mobile_head_forward(sd, route1, route2, max(x.shape[-2:]), anchors, n_class)
 
 
+def tiny_squeeze_forward(sd, x, anchors=TINY_ANCHORS, n_class=80):
+    """YOLOv3TinySqueeze.forward (eval) — yolov3_tiny_squeeze.py:71-104; encoder: oracle/squeezenet.py (parity
+    unpinned, see its header).  Both heads sit on the same grid: the concat takes no upsample (:77)."""
+    from .squeezenet import squeezenet_routes
+    img_size = max(x.shape[-2:])
+    route1, route2 = squeezenet_routes(sd, x)
+    b1 = conv_bn_leaky(sd, "sequence_branch1_1.branch1_conv1", route2)
+    b1 = conv_bn_leaky(sd, "sequence_branch1_2.branch1_conv2", torch.cat([route1, b1], 1))
+    b1 = plain_conv1x1(sd, "sequence_branch1_2.branch1_conv3", b1)
+    b2 = plain_conv1x1(sd, "sequence_branch2.branch2_conv2", conv_bn_leaky(sd, "sequence_branch2.branch2_conv1", route2))
+    outs = [yolo_decode(h, a, n_class, img_size) for h, a in zip((b1, b2), anchors)]
+    io, p = zip(*outs)
+    return torch.cat(io, 1), tuple(p)
+
+
 def yolov3_forward(sd, x, anchors=SPP_ANCHORS, n_class=80):
     """YOLOv3.forward (eval) — /root/reference/pytorch_yolo/models/yolov3.py:74-116.  Heads 1/2 end in a plain
     biased 1x1 conv (:38,:55); head 3 ends in a 3x3 ConvBlock (:70)."""

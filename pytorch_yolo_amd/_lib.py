@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("YOLO_HIP_LIB") or os.path.join(_HERE, "csrc", "libyolo_hip.so")   # override: A/B runs of two builds
 
-ACT_NONE, ACT_LEAKY01, ACT_RELU6 = 0, 1, 2
+ACT_NONE, ACT_LEAKY01, ACT_RELU6, ACT_RELU = 0, 1, 2, 3
 DT_BF16, DT_F32 = 0, 1
 OP_CONV, OP_MAXPOOL, OP_SPP, OP_DWCONV, OP_CONV1_NCHW, OP_RESUNIT, OP_STEM, OP_HEAD_DECODE, OP_CONV1_POOL = 1, 2, 3, 4, 5, 6, 7, 8, 9
 OP_MBCONV, OP_CONV_POOL = 10, 11

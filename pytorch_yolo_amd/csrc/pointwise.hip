@@ -226,8 +226,10 @@ extern "C" int yolo_maxpool_fwd(const void* x, void* y, int n, int h, int w, int
   YOLO_REQUIRE(in_c_total % 8 == 0 && in_c_offset % 8 == 0 && out_c_total % 8 == 0 && out_c_offset % 8 == 0,
                "maxpool: views must be 8-channel aligned");
   YOLO_REQUIRE(ksize >= 1 && stride >= 1 && dilation >= 1 && pad >= 0, "maxpool: bad geometry");
-  YOLO_REQUIRE(ho == (h + 2 * pad - dilation * (ksize - 1) - 1) / stride + 1 &&
-                   wo == (w + 2 * pad - dilation * (ksize - 1) - 1) / stride + 1,
+  // floor mode, or torch's ceil_mode (one more row / column whose window still starts inside the input or its left
+  // padding; the taps beyond the input count as -inf like the padding does)
+  const int hf = (h + 2 * pad - dilation * (ksize - 1) - 1) / stride + 1, wf = (w + 2 * pad - dilation * (ksize - 1) - 1) / stride + 1;
+  YOLO_REQUIRE((ho == hf || (ho == hf + 1 && (ho - 1) * stride < h + pad)) && (wo == wf || (wo == wf + 1 && (wo - 1) * stride < w + pad)),
                "maxpool: output %dx%d inconsistent with %dx%d k%d s%d p%d d%d", ho, wo, h, w, ksize, stride, pad, dilation);
   const long total = (long)n * ho * wo * (c / 8);
   hipLaunchKernelGGL(maxpool_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (bf16_t*)y, h,

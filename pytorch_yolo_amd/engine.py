@@ -27,7 +27,7 @@ from typing import List, Optional
 import torch
 
 from . import kernels as K
-from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU6, DT_BF16, DT_F32, OP_CONV, OP_CONV1_NCHW, OP_DWCONV,
+from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU, ACT_RELU6, DT_BF16, DT_F32, OP_CONV, OP_CONV1_NCHW, OP_DWCONV,
                    OP_CONV1_POOL, OP_CONV_POOL, OP_MBCONV, OP_HEAD_DECODE, OP_MAXPOOL, OP_RESUNIT, OP_SPP, OP_STEM, YoloOp)
 
 # which residual-unit widths run as ONE launch (bit mask of C: 64 | 128 | 256); see DESIGN.md §3.1d for the
@@ -90,12 +90,13 @@ class Recorder:
         return node
 
     # weight = (w_oihw f32, bias f32) already BN-folded; act in {'leaky','relu6','none'}
-    def conv(self, x: Sym, weight, stride=1, act="leaky", residual: Sym = None, want_preadd=False, f32_out=False):
+    def conv(self, x: Sym, weight, stride=1, act="leaky", residual: Sym = None, want_preadd=False, f32_out=False, pad=None):
         w, _ = weight
         cout, cin_w, k, _ = w.shape
         if cin_w > x.c:
             raise RuntimeError(f"conv expects {cin_w} input channels, tensor has {x.c}")
-        pad = (k - 1) // 2
+        same = (k - 1) // 2
+        pad = same if pad is None else pad
         ho, wo = (x.h + 2 * pad - k) // stride + 1, (x.w + 2 * pad - k) // stride + 1
         if not f32_out and cout % 8:
             raise RuntimeError(f"internal conv width {cout} is not a multiple of 8 (unsupported kernels_divider)")
@@ -105,6 +106,8 @@ class Recorder:
             outs.append(Sym(x.n, ho, wo, cout, slot=1))
         srcs = [x] + ([residual] if residual is not None else [])
         self._add("conv", srcs, outs, weight=weight, stride=stride, act=act, has_res=residual is not None)
+        if pad != same:
+            self.nodes[-1].attrs["pad"] = pad            # (SqueezeNet's unpadded first conv; no fused form takes it)
         return (y, outs[1]) if want_preadd else y
 
     def dwconv(self, x: Sym, weight, stride=1, act="relu6"):
@@ -114,14 +117,18 @@ class Recorder:
         self._add("dwconv", [x], [y], weight=weight, stride=stride, act=act)
         return y
 
-    def maxpool(self, x: Sym, size, stride):
+    def maxpool(self, x: Sym, size, stride, pad=None, ceil_mode=False):
         # reference MaxPool: (2,1) -> pad 1, dilation 2 (models/yolo_base.py:60-66)
         if size == 2 and stride == 1:
             pad, dil = 1, 2
         else:
-            pad, dil = (size - 1) // 2, 1
-        ho = (x.h + 2 * pad - dil * (size - 1) - 1) // stride + 1
-        wo = (x.w + 2 * pad - dil * (size - 1) - 1) // stride + 1
+            pad, dil = ((size - 1) // 2 if pad is None else pad), 1
+
+        def out(n):                                       # torch.nn.MaxPool2d output size incl. ceil_mode
+            span = n + 2 * pad - dil * (size - 1) - 1
+            o = (-(-span // stride) if ceil_mode else span // stride) + 1
+            return o - 1 if ceil_mode and (o - 1) * stride >= n + pad else o
+        ho, wo = out(x.h), out(x.w)
         y = Sym(x.n, ho, wo, x.c)
         self._add("pool", [x], [y], size=size, stride=stride, pad=pad, dil=dil)
         return y
@@ -146,7 +153,7 @@ class Recorder:
         self._add("head", [x], [])
 
 
-_ACT = {"leaky": ACT_LEAKY01, "relu6": ACT_RELU6, "none": ACT_NONE}
+_ACT = {"leaky": ACT_LEAKY01, "relu6": ACT_RELU6, "relu": ACT_RELU, "none": ACT_NONE}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -489,7 +496,7 @@ class Plan:
                                 cout=w.shape[0], out_c_total=dst.buf.c_total, out_c_offset=dst.c_offset,
                                 ksize=w.shape[2], stride=nd.attrs["stride"], act=_ACT[nd.attrs["act"]],
                                 kpad=kpad, cout_pad=cout_pad, upsample2x=1 if up is not None else 0,
-                                out_dtype=DT_F32 if y.f32 else DT_BF16,
+                                out_dtype=DT_F32 if y.f32 else DT_BF16, pad=nd.attrs.get("pad"),
                                 res=(res.buf.c_total, res.c_offset) if res is not None else (0, 0),
                                 aux=(aux.buf.c_total, aux.c_offset) if aux is not None else (0, 0))
                 op = YoloOp()

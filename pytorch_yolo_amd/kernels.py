@@ -63,8 +63,8 @@ def pack_input(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
 
 
 def conv_desc(*, n, h, w, cin, in_c_total, in_c_offset, cout, out_c_total, out_c_offset, ksize, stride,
-              act, kpad, cout_pad, upsample2x=0, out_dtype=DT_BF16, res=(0, 0), aux=(0, 0)) -> YoloConvDesc:
-    pad = (ksize - 1) // 2
+              act, kpad, cout_pad, upsample2x=0, out_dtype=DT_BF16, res=(0, 0), aux=(0, 0), pad=None) -> YoloConvDesc:
+    pad = (ksize - 1) // 2 if pad is None else pad
     d = YoloConvDesc()
     d.n, d.h, d.w, d.cin, d.in_c_total, d.in_c_offset = n, h, w, cin, in_c_total, in_c_offset
     d.ho, d.wo = (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1

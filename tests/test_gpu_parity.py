@@ -657,6 +657,26 @@ def test_mobilenet_variant_vs_oracle():
     _assert_model_close(io.cpu(), io_ref, "mobile_96x128", score_max=3e-2, score_rms=4e-3)
 
 
+@pytest.mark.parametrize("n,h,w", [(2, 127, 159), (1, 416, 416)])
+def test_squeezenet_variant_vs_oracle(n, h, w):
+    """YOLOv3TinySqueeze: unpadded stride-2 first conv, ReLU, ceil-mode 3x3/2 max pools (windows
+    that hang over the border), Fire modules written straight into their concat slices, two heads on one grid.  The
+    encoder oracle is a restatement of the published SqueezeNet 1.1 (torchvision absent: parity unpinned,
+    oracle/squeezenet.py)."""
+    from oracle import models as om
+    from pytorch_yolo_amd import YOLOv3TinySqueeze
+    from pytorch_yolo_amd.utils.synthetic import synth_images, synth_state_dict
+    model = YOLOv3TinySqueeze(n_class=3).eval()
+    sd = synth_state_dict(model.state_dict(), 5, n_class=3)
+    model.load_state_dict(sd)
+    x = synth_images(n, h, w, 3)
+    with torch.no_grad():
+        io_ref, p_ref = om.tiny_squeeze_forward(sd, x, om.TINY_ANCHORS, 3)
+        io, p = model.to(DEV)(x.to(DEV))
+    assert io.shape == io_ref.shape and [tuple(q.shape) for q in p] == [tuple(q.shape) for q in p_ref]
+    _assert_model_close(io.cpu(), io_ref, f"squeeze_{h}x{w}", score_max=3e-2, score_rms=4e-3)
+
+
 def test_mobilenet_fused_blocks_match_three_launch_path(monkeypatch):
     """Whole YOLOv3TinyMobile at 416x416, 8 images: the plan with the seven inverted-residual blocks fused
     (yolo_mbconv_fwd, thousands of tiles per launch: persistent loops, 4 / 2 / 1 workgroups per CU) against the plan

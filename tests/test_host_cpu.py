@@ -166,6 +166,30 @@ def test_planner_tiny_and_mobile():
     assert sum(1 for o in _ops(plan) if o.kind == OP_CONV and o.residual) == 7           # MobileNetV2 identity shortcuts of the wide blocks
 
 
+def test_planner_squeezenet_variant():
+    """YOLOv3TinySqueeze (reference models/yolov3_tiny_squeeze.py): torchvision's SqueezeNet 1.1 key names, the
+    unpadded first conv, ceil-mode pools and Fire modules that write their two expand convs into one concat buffer."""
+    from pytorch_yolo_amd import YOLOv3TinySqueeze
+    m = YOLOv3TinySqueeze().eval()
+    keys = list(m.state_dict().keys())
+    assert keys[:2] == ["features.sequence1.0.weight", "features.sequence1.0.bias"]
+    assert "features.sequence1.7.expand3x3.weight" in keys and "features.sequence2.3.squeeze.bias" in keys
+    assert m.state_dict()["features.sequence2.3.expand3x3.weight"].shape == (256, 64, 3, 3)
+    assert m.state_dict()["sequence_branch1_2.branch1_conv2.sequence.conv.weight"].shape == (128, 256 + 128, 3, 3)
+    plan = _dry_plan(m, 416)
+    ops = _ops(plan)
+    first = ops[0].conv
+    assert (first.ksize, first.stride, first.pad, first.ho, first.act) == (3, 2, 0, 207, _lib.ACT_RELU)
+    pools = [o.conv for o in ops if o.kind == OP_MAXPOOL]
+    assert [(p.h, p.ho, p.ksize, p.stride, p.pad) for p in pools] == [(207, 103, 3, 2, 0), (103, 51, 3, 2, 0), (51, 25, 3, 2, 0)]
+    convs = [o for o in ops if o.kind == OP_CONV]
+    # 1 stem + 8 fires x 3 convs + 3 ConvBlocks of the head; the two heads decode in their conv epilogue
+    assert len(convs) == 1 + 24 + 3 and sum(1 for o in ops if o.kind == OP_HEAD_DECODE) == 2
+    fire_out = [(o.conv.out_c_total, o.conv.out_c_offset) for o in convs if o.conv.cin == 16 and o.conv.h == 103][:2]
+    assert fire_out == [(128, 0), (128, 64)]                       # expand1x1 | expand3x3 share the concat buffer
+    assert plan.rows_total == 2 * 3 * 25 * 25 and [h["stride"] for h in plan.heads] == [416 / 25, 416 / 25]
+
+
 def test_unsupported_widths_fail_loudly():
     m = YOLOv3SPP(anchors=C.SPP_ANCHORS, kernels_divider=8).eval()
     with pytest.raises(RuntimeError, match="multiple of 8"):
