@@ -402,6 +402,17 @@ def test_maxpool_exact(k, s):
     assert torch.equal(got, max_pool(x, k, s))
 
 
+@pytest.mark.parametrize("h,w", [(10, 13), (64, 80), (7, 7), (103, 51)])
+def test_maxpool_ceil_mode_exact(h, w):
+    """MaxPool2d(3, 2, ceil_mode=True) of the SqueezeNet encoder: when (size - 3) is odd torch adds a row / column whose
+    window hangs over the border (those taps are -inf).  Exact, through engine.Recorder.maxpool and yolo_maxpool_fwd."""
+    from pytorch_yolo_amd import engine
+    x = _bf16r(torch.randn(2, 16, h, w))
+    want = F.max_pool2d(x, 3, 2, ceil_mode=True)
+    got = engine.run_standalone(lambda g, s: g.maxpool(s, 3, 2, pad=0, ceil_mode=True), x.to(DEV)).cpu()
+    assert got.shape == want.shape and torch.equal(got, want)
+
+
 def test_maxpool21_kat():
     from pytorch_yolo_amd.models.yolo_base import MaxPool
     x = torch.arange(16.).view(1, 1, 4, 4).repeat(1, 8, 1, 1)
@@ -657,7 +668,7 @@ def test_mobilenet_variant_vs_oracle():
     _assert_model_close(io.cpu(), io_ref, "mobile_96x128", score_max=3e-2, score_rms=4e-3)
 
 
-@pytest.mark.parametrize("n,h,w", [(2, 127, 159), (1, 416, 416)])
+@pytest.mark.parametrize("n,h,w", [(2, 127, 159), (1, 416, 416), (1, 130, 162)])
 def test_squeezenet_variant_vs_oracle(n, h, w):
     """YOLOv3TinySqueeze: unpadded stride-2 first conv, ReLU, ceil-mode 3x3/2 max pools (windows
     that hang over the border), Fire modules written straight into their concat slices, two heads on one grid.  The
