@@ -78,7 +78,8 @@ YOLO_API int yolo_conv2d_fwd(const void* x, const void* w_packed, const float* b
                     void* y, void* y_preadd, const YoloConvDesc* d, yolo_stream_t s);
 
 /* First layer fused with the input packing: x is the caller's f32 NCHW batch [n,cin_real,h,w] (cin_real <= 8),
- * w_packed / bias as for yolo_conv2d_fwd with d->cin = 8; 3x3, stride 1, cout 32, bf16 NHWC output. */
+ * w_packed / bias as for yolo_conv2d_fwd with d->cin = 8; 3x3 / pad 1, bf16 NHWC output: stride 1 with cout 16 or 32
+ * (Darknet), or stride 2 with cout 32 (MobileNetV2's first layer). */
 YOLO_API int yolo_conv1_nchw_f32_fwd(const float* x_nchw, int cin_real, const void* w_packed, const float* bias,
                                      void* y, const YoloConvDesc* d, yolo_stream_t s);
 /* same, followed by MaxPool2d(2, 2) (the first ConvPoolBlock of YOLOv3-tiny, models/yolo_base.py:69-80 with

@@ -692,7 +692,9 @@ static int conv1_nchw(const float* x_nchw, int cin_real, const void* w_packed, c
   const YoloConvDesc& d = *dp;
   YOLO_REQUIRE(cin_real >= 1 && cin_real <= 8 && d.cin == 8, "conv1: 1..8 input channels (packed K uses cin = 8)");
   YOLO_REQUIRE(d.out_c_offset % 8 == 0 && d.out_c_total % 8 == 0 && d.out_c_offset + d.cout <= d.out_c_total, "conv1: bad output view");
-  YOLO_REQUIRE(d.ho == d.h && d.wo == d.w, "conv1: 3x3 / stride 1 / pad 1 only");
+  YOLO_REQUIRE((d.stride == 1 && d.ho == d.h && d.wo == d.w) ||
+                   (d.stride == 2 && !pool && d.ho == (d.h - 1) / 2 + 1 && d.wo == (d.w - 1) / 2 + 1),
+               "conv1: 3x3 / pad 1 at stride 1, or at stride 2 (cout 32, no pool) only");
   ConvArgs a;
   a.x = nullptr;
   a.w = (const bf16_t*)w_packed;
@@ -708,8 +710,9 @@ static int conv1_nchw(const float* x_nchw, int cin_real, const void* w_packed, c
   a.w_bytes = 0;
   a.debug = 0;
   YOLO_SET_STAMPS(a);
-  const int rc = launch_conv1_nchw(a, x_nchw, cin_real, pool, (hipStream_t)s);
-  if (rc == 1) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv1: shape not covered (3x3 s1, cout 16 or 32, bf16 out)");
+  const int rc = d.stride == 2 ? launch_conv1_s2_nchw(a, x_nchw, cin_real, (hipStream_t)s)
+                               : launch_conv1_nchw(a, x_nchw, cin_real, pool, (hipStream_t)s);
+  if (rc == 1) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv1: shape not covered (3x3 s1 with cout 16 or 32, 3x3 s2 with cout 32; bf16 out)");
   return rc;
 }
 

@@ -167,6 +167,119 @@ __global__ __launch_bounds__(COUT * 8) void conv3x3_small_kernel(const ConvArgs 
   }
 }
 
+// First layer at stride 2 (MobileNetV2's ConvBNReLU(3, 32, stride=2), yolov3_tiny_mobilenet.py:14-46 via torchvision):
+// float32 NCHW batch -> 3x3 / stride 2 / pad 1 conv -> 32 channels bf16 NHWC, without the packed NHWC copy of the input
+// (conv1_nchw_kernel of conv3x3_halo.hip is the stride-1 form).  16x16 output tiles, 33x33 input halo.
+template <int CINR>
+__global__ __launch_bounds__(256) void conv1_s2_nchw_kernel(const ConvArgs a, const float* __restrict__ x_nchw, int cin_real_arg) {
+  const int cin_real = CINR ? CINR : cin_real_arg;
+  constexpr int HW2 = 33, HP = 33 * 33, TM = 64, NPX = (HP + 255) / 256, TPB = 5;
+  constexpr int SP = 32 * 2 + 16;
+  constexpr int HALO_B = ((HP * 16 + 1023) / 1024) * 1024;    // 17 KB
+  __shared__ __attribute__((aligned(16))) char smem[2 * HALO_B + 4 * TM * SP];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const YoloConvDesc& d = a.d;
+  const int tiles_x = (d.wo + 15) / 16, tiles_y = (d.ho + 15) / 16;
+  const int groups_x = (tiles_x + TPB - 1) / TPB;
+  int swz = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tx0 = (swz % groups_x) * TPB;
+  swz /= groups_x;
+  const int oy0 = (swz % tiles_y) * 16;
+  const int b = swz / tiles_y;
+  const int n_t = min(TPB, tiles_x - tx0);
+
+  const int r32 = lane & 31, khalf = lane >> 5;
+  bf16x8 wf[5];
+#pragma unroll
+  for (int ks = 0; ks < 5; ++ks) wf[ks] = *reinterpret_cast<const bf16x8*>(a.w + (long)r32 * d.kpad + ks * 16 + khalf * 8);
+  f32x4 bias4[4];
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) bias4[g4] = *reinterpret_cast<const f32x4*>(a.bias + g4 * 8 + khalf * 4);
+
+  // halo pixels owned by this thread (5 of the 1089), prefetched one tile ahead into registers
+  const long plane = (long)d.h * d.w;
+  int hy[NPX], hx[NPX];
+#pragma unroll
+  for (int u = 0; u < NPX; ++u) {
+    const int hp = tid + u * 256;
+    hy[u] = hp / HW2;
+    hx[u] = hp - hy[u] * HW2;
+  }
+  float pre[NPX][CINR ? CINR : 8];
+  auto fetch = [&](int t) {
+    const int ix0 = (tx0 + t) * 32 - 1, iy0 = oy0 * 2 - 1;
+#pragma unroll
+    for (int u = 0; u < NPX; ++u) {
+      const int yy = iy0 + hy[u], xx = ix0 + hx[u];
+      const bool ok = tid + u * 256 < HP && (unsigned)yy < (unsigned)d.h && (unsigned)xx < (unsigned)d.w;
+      const float* src = x_nchw + ((long)b * cin_real) * plane + (long)yy * d.w + xx;
+#pragma unroll
+      for (int e = 0; e < (CINR ? CINR : 8); ++e) pre[u][e] = (ok && e < cin_real) ? src[e * plane] : 0.f;
+    }
+  };
+  auto commit = [&](int hb) {                                  // registers -> LDS halo buffer as NHWC8 bf16
+    char* const hbuf = smem + hb * HALO_B;
+#pragma unroll
+    for (int u = 0; u < NPX; ++u) {
+      if (tid + u * 256 >= HP) continue;
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = e < (CINR ? CINR : 8) ? (bf16_t)pre[u][e < (CINR ? CINR : 8) ? e : 0] : (bf16_t)0.f;
+      *reinterpret_cast<bf16x8*>(hbuf + (tid + u * 256) * 16) = v;
+    }
+  };
+
+  char* const stg = smem + 2 * HALO_B + wave * (TM * SP);
+  fetch(0);
+  for (int t = 0; t < n_t; ++t) {
+    commit(t & 1);
+    __syncthreads();                       // halo t visible; everyone is past the reads of halo t-2's buffer
+    if (t + 1 < n_t) fetch(t + 1);
+    const char* const hbuf = smem + (t & 1) * HALO_B;
+    const int ox0 = (tx0 + t) * 16;
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+      int tap = ks * 2 + khalf;
+      if (tap > 8) tap = 8;                                   // tap 9 has zero weights: read any valid pixel
+      const int dh = (tap * 11) >> 5, dw = tap - 3 * dh;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int q = wave * TM + j * 32 + r32;
+        const int hr = ((q >> 4) * 2 + dh) * HW2 + (q & 15) * 2 + dw;
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(hbuf + hr * 16);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf, acc[j], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)apply_act(acc[j][g4 * 4 + e] + bias4[g4][e], d.act);
+        *reinterpret_cast<bf16x4*>(stg + (j * 32 + r32) * SP + (g4 * 8 + khalf * 4) * 2) = o;
+      }
+    __builtin_amdgcn_wave_barrier();
+    bf16_t* const ybase = reinterpret_cast<bf16_t*>(a.y) + d.out_c_offset + (lane & 3) * 8;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int row = pass * 16 + (lane >> 2);
+      const int q = wave * TM + row;
+      const int yy = oy0 + (q >> 4), xx = ox0 + (q & 15);
+      if (yy < d.ho && xx < d.wo)
+        *reinterpret_cast<u32x4*>(ybase + ((long)(b * d.ho + yy) * d.wo + xx) * d.out_c_total) =
+            *reinterpret_cast<const u32x4*>(stg + row * SP + (lane & 3) * 16);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 template <int CIN, int COUT, bool POOL>
 int launch_small_p(const ConvArgs& a, hipStream_t s) {
   constexpr int lds = ((18 * 18 * (CIN * 2 + (CIN == 32 ? YOLO_SMALL_PAD32 : 0)) + 1023) / 1024) * 1024 + (COUT / 8) * 64 * (32 * 2 + 16);
@@ -191,6 +304,19 @@ int launch_small(const ConvArgs& a, bool pool, hipStream_t s) {
 }
 
 }  // namespace
+
+// float32 NCHW input -> first conv layer at stride 2 (cout 32, pad 1).  Returns 1 if the shape is not covered.
+int yolo_conv::launch_conv1_s2_nchw(const ConvArgs& a, const float* x_nchw, int cin_real, hipStream_t s) {
+  const YoloConvDesc& d = a.d;
+  if (d.ksize != 3 || d.stride != 2 || d.pad != 1 || d.cin != 8 || cin_real > 8 || d.cout != 32 || d.upsample2x ||
+      d.out_dtype != YOLO_DT_BF16 || d.kpad < 80 || a.res || a.aux)
+    return 1;
+  const long grid = (long)d.n * ((d.ho + 15) / 16) * (((d.wo + 15) / 16 + 4) / 5);
+  if (grid > 0x7fffffffL) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv1 grid too large");
+  if (cin_real == 3) hipLaunchKernelGGL((conv1_s2_nchw_kernel<3>), dim3((unsigned)grid), dim3(256), 0, s, a, x_nchw, cin_real);
+  else hipLaunchKernelGGL((conv1_s2_nchw_kernel<0>), dim3((unsigned)grid), dim3(256), 0, s, a, x_nchw, cin_real);
+  return yolo_check_launch("yolo_conv1_nchw_f32_fwd(stride 2)");
+}
 
 extern "C" int yolo_conv3x3_pool_supported(int cin, int cout) { return (cin == 16 || cin == 32) && (cout == 32 || cout == 64); }
 

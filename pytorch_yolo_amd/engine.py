@@ -334,12 +334,14 @@ class Plan:
         nd = x.consumers[0]
         w, _ = nd.attrs["weight"]
         y = nd.outs[0]
-        ok = (w.shape[0] in (16, 32) and w.shape[2] == 3 and nd.attrs["stride"] == 1 and not nd.attrs["has_res"]
+        s1 = w.shape[0] in (16, 32) and nd.attrs["stride"] == 1
+        s2 = w.shape[0] == 32 and nd.attrs["stride"] == 2 and os.environ.get("YOLO_FUSE_CONV1_S2", "1") == "1"   # MobileNetV2
+        ok = ((s1 or s2) and w.shape[2] == 3 and "pad" not in nd.attrs and not nd.attrs["has_res"]
               and len(nd.outs) == 1 and "up_into" not in nd.attrs and not y.f32 and y.buf is not None
               and y.c_offset % 8 == 0)
         if ok and x.buf in self._bufs:
             self._bufs.remove(x.buf)          # no packed input buffer needed
-        if ok:
+        if ok and s1:
             self._try_fuse_stem(nd)
             if "fused_away" not in nd.attrs:
                 self._try_fuse_pool(nd)

@@ -162,7 +162,10 @@ def test_planner_tiny_and_mobile():
         (32, 32, 16, 1, 208, False, 0), (16, 96, 24, 2, 208, True, 0), (24, 144, 24, 1, 104, True, 1), (24, 144, 32, 2, 104, True, 0),
         (32, 192, 32, 1, 52, True, 1), (32, 192, 32, 1, 52, True, 1), (32, 192, 64, 2, 52, True, 0)]
     assert all(o.y != o.x and o.w_dw and o.bias_dw for o in mb)
-    assert kinds.count(OP_DWCONV) == 10 and kinds.count(OP_CONV) == 25 and kinds.count(OP_HEAD_DECODE) == 2 and not plan.fused_input   # stride-2 stem: generic path
+    # the stride-2 first layer reads the NCHW f32 batch itself (yolo_conv1_nchw_f32_fwd, stride-2 form)
+    first = _ops(plan)[0]
+    assert plan.fused_input and first.kind == OP_CONV1_NCHW and (first.conv.stride, first.conv.cout, first.conv.ho) == (2, 32, 208)
+    assert kinds.count(OP_DWCONV) == 10 and kinds.count(OP_CONV) == 24 and kinds.count(OP_HEAD_DECODE) == 2
     assert sum(1 for o in _ops(plan) if o.kind == OP_CONV and o.residual) == 7           # MobileNetV2 identity shortcuts of the wide blocks
 
 
