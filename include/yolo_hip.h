@@ -77,6 +77,19 @@ typedef struct YoloConvDesc {
 YOLO_API int yolo_conv2d_fwd(const void* x, const void* w_packed, const float* bias, const void* residual,
                     void* y, void* y_preadd, const YoloConvDesc* d, yolo_stream_t s);
 
+/* Split-K form for layers with few pixels and a long K (3x3 256 -> 512 on 13x13, 3x3 1280 -> 64 on 13x13: fewer tiles than
+ * half the CUs): `splits` workgroups share a tile's K range, write fp32 partials to `workspace` and the last one to
+ * arrive (counters, zero-initialised once by the caller, self-resetting) sums them in split order and runs the normal
+ * epilogue - deterministic.  yolo_conv2d_splitk_plan() says whether a layer takes it (splits >= 2) and how much
+ * workspace / how many int32 counters it needs; layers it declines go through yolo_conv2d_fwd.
+ * EXPERIMENTAL: exact, but slower than the plain launch on MI355X today (the partial exchange crosses XCD L2s); the
+ * engine only uses it with YOLO_SPLITK=1. */
+YOLO_API int yolo_conv2d_splitk_plan(const YoloConvDesc* d, int has_residual, int has_preadd, int* splits, size_t* ws_bytes,
+                                     int* n_counters);
+YOLO_API int yolo_conv2d_splitk_fwd(const void* x, const void* w_packed, const float* bias, const void* residual, void* y,
+                                    void* y_preadd, const YoloConvDesc* d, int splits, void* workspace, size_t ws_bytes,
+                                    int32_t* counters, yolo_stream_t s);
+
 /* First layer fused with the input packing: x is the caller's f32 NCHW batch [n,cin_real,h,w] (cin_real <= 8),
  * w_packed / bias as for yolo_conv2d_fwd with d->cin = 8; 3x3 / pad 1, bf16 NHWC output: stride 1 with cout 16 or 32
  * (Darknet), or stride 2 with cout 32 (MobileNetV2's first layer). */
@@ -226,6 +239,8 @@ typedef struct YoloOp {
      w_dw/bias_dw = the depthwise conv; geometry from conv (n,h,w,cin,views,cout,stride), hidden = kpad_pre,
      has_res = conv.res_c_total != 0 */
   const float* w_dw; const float* bias_dw;
+  /* CONV with splits >= 2: yolo_conv2d_splitk_fwd */
+  void* workspace; int32_t* counters; size_t ws_bytes; int32_t splits, _pad3;
 } YoloOp;
 YOLO_API int yolo_run_ops(const YoloOp* ops, int n_ops, yolo_stream_t s);
 

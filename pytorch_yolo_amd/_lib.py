@@ -34,7 +34,9 @@ class YoloOp(C.Structure):
                 ("head_anchors_px", C.c_float * 8), ("head_stride_px", C.c_float),
                 ("head_na", C.c_int32), ("head_nc", C.c_int32), ("io_rows_total", C.c_int32),
                 ("io_row_offset", C.c_int32), ("_pad2", C.c_int32),
-                ("w_dw", C.c_void_p), ("bias_dw", C.c_void_p)]
+                ("w_dw", C.c_void_p), ("bias_dw", C.c_void_p),
+                ("workspace", C.c_void_p), ("counters", C.c_void_p), ("ws_bytes", C.c_size_t),
+                ("splits", C.c_int32), ("_pad3", C.c_int32)]
 
 
 class YoloMbconvDesc(C.Structure):
@@ -49,6 +51,10 @@ SIGNATURES = {
     "yolo_abi_version": (C.c_int, []),
     "yolo_pack_input_nchw_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
     "yolo_conv2d_fwd": (C.c_int, [C.c_void_p] * 6 + [C.POINTER(YoloConvDesc), C.c_void_p]),
+    "yolo_conv2d_splitk_plan": (C.c_int, [C.POINTER(YoloConvDesc), C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t),
+                                          C.POINTER(C.c_int)]),
+    "yolo_conv2d_splitk_fwd": (C.c_int, [C.c_void_p] * 6 + [C.POINTER(YoloConvDesc), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
+                                         C.c_void_p]),
     "yolo_conv1_nchw_f32_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.POINTER(YoloConvDesc), C.c_void_p]),
     "yolo_conv1_pool_nchw_f32_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

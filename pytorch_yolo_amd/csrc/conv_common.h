@@ -28,6 +28,12 @@ struct ConvArgs {
   int steps;    // kpad / 32
   uint32_t x_bytes, w_bytes;
   HeadDecodeArgs hd;   // DECODE instances only
+  // split-K launches (conv_igemm_bf16_kernel<..., SPLITK>): grid.y = splits, `steps` = K steps PER split; every split
+  // writes its fp32 partial tile to ws[split][M][cout], the last one to arrive at a tile (cnt[tile], self-resetting)
+  // adds the partials in split order and runs the normal epilogue
+  int splits;
+  float* ws;
+  int* cnt;
   int debug;    // YOLO_CONV_DEBUG, tuning / ablation only (results are wrong with bits 1..8 set):
                 //   1 no pixel DMA   2 no weight DMA   4 no MFMA   8 no epilogue   16 no LDS-staged epilogue
                 //   32 no halo kernel   128 no 128x256 tiles   256 no loader waves   512 8-wave 256x256 tiles

@@ -46,8 +46,9 @@ namespace {
 // LDS_EPI (bf16 output, cout % 32 == 0): the finished tile goes registers -> LDS (fp32) -> global so that
 // residual read, pre-add copy and store are 16-byte-per-lane accesses over whole channel runs.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int NS, bool FAST, bool LDS_EPI, bool MFMA16 = false, bool DECODE = false,
-          int NP = 0>
+          int NP = 0, bool SPLITK = false>
 __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NP)) void conv_igemm_bf16_kernel(const ConvArgs a) {
+  static_assert(!SPLITK || (FAST && LDS_EPI && MFMA16 && !DECODE), "split-K: 16x16x32 path with the LDS epilogue");
   constexpr int NW = WAVES_M * WAVES_N;
   // NP > 0: NP extra LOADER waves issue every LDS-DMA of the block; the NW MFMA waves only read LDS and multiply
   // (an LDS-DMA costs its issuing wave 60-180 cycles: ablation in DESIGN.md 3.1c).  NL = number of loader waves.
@@ -141,6 +142,14 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NP)) void conv_igemm_bf16
   // generic: this lane's chunk has its own (tap, channel); FAST: both are wave-uniform scalars
   int tap = FAST ? 0 : (chunk * 8) / d.cin;
   int kc = FAST ? 0 : chunk * 8 - tap * d.cin;
+  if constexpr (SPLITK) {      // this workgroup multiplies K steps [blockIdx.y * steps, + steps): start tap / channel, weight columns
+    const int k0 = blockIdx.y * a.steps * BK;
+    tap = k0 / d.cin;
+    kc = k0 - tap * d.cin;
+#pragma unroll
+    for (int it = 0; it < WIT; ++it)
+      if (w_off[it] != kOobOffset) w_off[it] += (uint32_t)k0 * 2u;
+  }
 
   // One stage = LPS LDS-DMA instructions per thread (PIT pixel pieces, then WIT weight pieces).
   // issue(buf, step, lo, hi) launches pieces [lo, hi) so that the main loop can spread them between
@@ -447,6 +456,47 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NP)) void conv_igemm_bf16
     }
   } else if constexpr (LDS_EPI && MFMA16) {
     __syncthreads();
+    if constexpr (SPLITK) {
+      // partial tile -> ws[split]; lane = pixel (lane & 15), 4 consecutive couts 4 * (lane >> 4) + e of 16x16 tile (i, j)
+      const int c16 = lane & 15, q4 = lane >> 4;
+      const long slice = (long)a.M * d.cout;
+      auto at = [&](int i, int j) -> long {
+        const int pix = m0 + wm * TM + j * 16 + c16, c = n0 + wn * TN + i * 16 + q4 * 4;
+        return (pix < a.M && c < d.cout) ? (long)pix * d.cout + c : -1L;
+      };
+      // The exchange goes through agent-scope (write-through / L2-bypassing) accesses: the eight XCD L2s are not coherent
+      // with each other for plain accesses, and a __threadfence() here writes back and invalidates the whole L2 of
+      // the XCD for every workgroup (measured: 3 x slower than not splitting at all).
+      float* const mine = a.ws + blockIdx.y * slice;
+#pragma unroll
+      for (int i = 0; i < MI16; ++i)
+#pragma unroll
+        for (int j = 0; j < NI16; ++j) {
+          const long o = at(i, j);
+          if (o >= 0)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) __hip_atomic_store(mine + o + e, acc16[i][j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      wait_vmcnt<0>();                       // this wave's partial stores have been acknowledged
+      __syncthreads();                       // ... and every wave's
+      __shared__ int s_last;
+      if (tid == 0) s_last = __hip_atomic_fetch_add(a.cnt + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.splits - 1;
+      __syncthreads();
+      if (!s_last) return;
+#pragma unroll
+      for (int i = 0; i < MI16; ++i)
+#pragma unroll
+        for (int j = 0; j < NI16; ++j) {
+          const long o = at(i, j);
+          f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+          if (o >= 0)
+            for (int z = 0; z < a.splits; ++z)        // fixed order: the result does not depend on who arrives last
+#pragma unroll
+              for (int e = 0; e < 4; ++e) sum[e] += __hip_atomic_load(a.ws + z * slice + o + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          acc16[i][j] = sum;
+        }
+      if (tid == 0) __hip_atomic_store(a.cnt + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
     epilogue_lds16<MI, NI16, TM>(a, acc16, smem + wave * (TM * kEpiPitch), lane, n0 + wn * TN, pix_of);
   } else if constexpr (LDS_EPI) {
     __syncthreads();                                 // every wave is done with the last stage: LDS is free
@@ -523,7 +573,7 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NP)) void conv_igemm_bf16
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BK, int NS, bool FAST, bool LDS_EPI, bool MFMA16 = false, bool DECODE = false,
-          int NP = 0>
+          int NP = 0, bool SPLITK = false>
 int launch_cfg(const ConvArgs& a, hipStream_t s) {
   const int m_tiles = (a.M + BM - 1) / BM;
   ConvArgs b = a;
@@ -531,13 +581,45 @@ int launch_cfg(const ConvArgs& a, hipStream_t s) {
   b.steps = (a.d.ksize * a.d.ksize * a.d.cin + BK - 1) / BK;   // kpad >= steps*BK: the K tail is zero-padded
   const long grid = (long)m_tiles * b.n_tiles;
   if (grid > 0x7fffffffL) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv grid too large");
-  hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, BK, NS, FAST, LDS_EPI, MFMA16, DECODE, NP>), dim3((unsigned)grid),
-                     dim3(64 * (WAVES_M * WAVES_N + NP)), 0, s, b);
+  unsigned gy = 1;
+  if constexpr (SPLITK) {
+    YOLO_REQUIRE(a.splits >= 2 && b.steps % a.splits == 0 && a.ws && a.cnt, "split-K: %d K steps do not split %d ways", b.steps, a.splits);
+    b.steps /= a.splits;
+    gy = (unsigned)a.splits;
+  }
+  hipLaunchKernelGGL((conv_igemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, BK, NS, FAST, LDS_EPI, MFMA16, DECODE, NP, SPLITK>),
+                     dim3((unsigned)grid, gy), dim3(64 * (WAVES_M * WAVES_N + NP)), 0, s, b);
   return yolo_check_launch("yolo_conv2d_fwd");
 }
 
 int conv_variant_override = -1;
 int conv_debug_flags = 0;   // tuning hook (YOLO_CONV_VARIANT), see yolo_conv2d_launch
+
+// split-K request of the current yolo_conv2d_splitk_fwd call (consumed by conv2d_launch_ex)
+struct SplitK {
+  int splits = 1;
+  float* ws = nullptr;
+  int* cnt = nullptr;
+};
+thread_local SplitK g_splitk;
+
+// The two shapes split-K serves (few pixels, long K, so few tiles that most CUs idle): tiles and K steps of the tile
+// configuration the dispatch below picks, or 0 tiles when the layer is not one of them.
+void splitk_shape(const YoloConvDesc& d, bool has_res_or_aux_views_ok, long* tiles, int* steps) {
+  *tiles = 0;
+  *steps = 0;
+  const long M = (long)d.n * d.ho * d.wo;
+  const bool epi = d.out_dtype == YOLO_DT_BF16 && d.cout % 32 == 0 && d.out_c_offset % 8 == 0 && d.out_c_total % 8 == 0 && has_res_or_aux_views_ok;
+  if (!epi || d.cin % 64 != 0 || d.upsample2x || (long)d.h * d.w >= 80 * 80) return;
+  if (d.cout == 64 && (M + 255) / 256 < 128) {                       // 64x64 tiles, BK 64
+    *tiles = (M + 63) / 64;
+    *steps = d.ksize * d.ksize * d.cin / 64;
+  } else if (d.ksize == 3 && d.stride == 1 && d.cout % 256 == 0 && ((M + 255) / 256) * (d.cout / 256) < 160 &&
+             ((M + 127) / 128) * (d.cout / 256) <= 256) {            // 128x256 loader-wave tiles, BK 64
+    *tiles = ((M + 127) / 128) * (d.cout / 256);
+    *steps = 9 * d.cin / 64;
+  }
+}
 
 }  // namespace
 
@@ -593,6 +675,9 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
   a.x_bytes = (uint32_t)x_bytes;
   a.w_bytes = (uint32_t)w_bytes;
   a.debug = conv_debug_flags;
+  a.splits = g_splitk.splits;
+  a.ws = g_splitk.ws;
+  a.cnt = g_splitk.cnt;
   YOLO_SET_STAMPS(a);
   if (hd) {   // head conv with the YOLOLayer decode as its epilogue: one 64-pixel x 256-cout tile per block
     a.hd = *hd;
@@ -618,6 +703,7 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
   // CUs idle, 64x64 tiles quadruple the workgroup count
   // ... and with one small workgroup per CU nothing hides the LDS-DMA latency of a two-stage ring: four stages
   if (d.cout == 64 && fast64 && epi && (M + 255) / 256 < 128 && conv_variant_override < 0 && !(conv_debug_flags & 2048)) {
+    if (a.splits > 1) return launch_cfg<64, 64, 2, 2, 64, 4, true, true, true, false, 0, true>(a, s);
     if (conv_debug_flags & 4194304) return launch_cfg<64, 64, 2, 2, 64, 2, true, true, true>(a, s);
     return launch_cfg<64, 64, 2, 2, 64, 4, true, true, true>(a, s);
   }
@@ -655,6 +741,7 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
         // ... and a THREE-stage ring: a K step of this tile is ~0.9 us of MFMA, less than an HBM round trip, and in the
         // model the weights of these layers (9.4 MB each) come from HBM: 0.094 -> 0.075 ms per layer inside the network
         // (nothing in a back-to-back micro-benchmark, where they sit in the Infinity Cache).  Bit 16384: two stages.
+        if (d.ksize == 3 && a.splits > 1) return launch_cfg<128, 256, 2, 4, 64, 3, true, true, true, false, 4, true>(a, s);
         if (d.ksize == 3 && !(conv_debug_flags & (256 | 16384))) return launch_cfg<128, 256, 2, 4, 64, 3, true, true, true, false, 4>(a, s);
         if (d.ksize == 3 && !(conv_debug_flags & 256)) return launch_cfg<128, 256, 2, 4, 64, 2, true, true, true, false, 4>(a, s);
         if (d.ksize == 1) return launch_cfg<128, 256, 2, 8, 64, 3, true, true, true>(a, s);   // 16 waves (-7..12 % on the 40x40 1x1 layers), 3 stages
@@ -709,6 +796,9 @@ static int conv1_nchw(const float* x_nchw, int cin_real, const void* w_packed, c
   a.x_bytes = 0;
   a.w_bytes = 0;
   a.debug = 0;
+  a.splits = 1;
+  a.ws = nullptr;
+  a.cnt = nullptr;
   YOLO_SET_STAMPS(a);
   const int rc = d.stride == 2 ? launch_conv1_s2_nchw(a, x_nchw, cin_real, (hipStream_t)s)
                                : launch_conv1_nchw(a, x_nchw, cin_real, pool, (hipStream_t)s);
@@ -729,6 +819,50 @@ extern "C" int yolo_conv1_pool_nchw_f32_fwd(const float* x_nchw, int cin_real, c
 extern "C" int yolo_conv2d_fwd(const void* x, const void* w_packed, const float* bias, const void* residual, void* y,
                                void* y_preadd, const YoloConvDesc* d, yolo_stream_t s) {
   return yolo_conv2d_launch(x, w_packed, bias, residual, y, y_preadd, d, (hipStream_t)s);
+}
+
+// Split-K form of yolo_conv2d_fwd for layers with few pixels and a long K (see splitk_shape).
+extern "C" int yolo_conv2d_splitk_plan(const YoloConvDesc* dp, int has_residual, int has_preadd, int* splits, size_t* ws_bytes,
+                                       int* n_counters) {
+  YOLO_REQUIRE(dp && splits && ws_bytes && n_counters, "splitk_plan: null pointer");
+  const YoloConvDesc& d = *dp;
+  *splits = 1;
+  *ws_bytes = 0;
+  *n_counters = 0;
+  const bool views_ok = (!has_residual || (d.res_c_offset % 8 == 0 && d.res_c_total % 8 == 0)) &&
+                        (!has_preadd || (d.aux_c_offset % 8 == 0 && d.aux_c_total % 8 == 0));
+  long tiles;
+  int steps;
+  splitk_shape(d, views_ok, &tiles, &steps);
+  if (tiles == 0 || tiles >= 200) return 0;
+  int best = 1;
+  for (int sp = 2; sp <= 8; ++sp)
+    if (steps % sp == 0 && steps / sp >= 6 && tiles * sp <= 256) best = sp;   // one workgroup per CU: more would queue
+  if (best > 1) {
+    *splits = best;
+    *ws_bytes = (size_t)best * d.n * d.ho * d.wo * d.cout * sizeof(float);
+    *n_counters = (int)tiles;
+  }
+  return 0;
+}
+
+extern "C" int yolo_conv2d_splitk_fwd(const void* x, const void* w_packed, const float* bias, const void* residual, void* y,
+                                      void* y_preadd, const YoloConvDesc* d, int splits, void* workspace, size_t ws_bytes,
+                                      int32_t* counters, yolo_stream_t s) {
+  YOLO_REQUIRE(d && splits >= 2 && workspace && counters, "splitk: bad arguments");
+  int want;
+  size_t need;
+  int ncnt;
+  const int rc0 = yolo_conv2d_splitk_plan(d, residual != nullptr, y_preadd != nullptr, &want, &need, &ncnt);
+  if (rc0) return rc0;
+  YOLO_REQUIRE(want >= 2, "splitk: this layer does not take a split-K launch");
+  YOLO_REQUIRE((size_t)splits * d->n * d->ho * d->wo * d->cout * sizeof(float) <= ws_bytes, "splitk: workspace too small");
+  g_splitk.splits = splits;
+  g_splitk.ws = (float*)workspace;
+  g_splitk.cnt = counters;
+  const int rc = yolo_conv2d_launch(x, w_packed, bias, residual, y, y_preadd, d, (hipStream_t)s);
+  g_splitk = SplitK();
+  return rc;
 }
 
 // Head conv + decode in one launch (see the DECODE epilogue of conv_igemm_bf16_kernel).

@@ -24,7 +24,9 @@ extern "C" int yolo_run_ops(const YoloOp* ops, int n_ops, yolo_stream_t s) {
     int rc;
     switch (o.kind) {
       case YOLO_OP_CONV:
-        rc = yolo_conv2d_launch(o.x, o.w, o.bias, o.residual, o.y, o.y_aux, &d, (hipStream_t)s);
+        rc = o.splits >= 2 ? yolo_conv2d_splitk_fwd(o.x, o.w, o.bias, o.residual, o.y, o.y_aux, &d, o.splits, o.workspace, o.ws_bytes,
+                                                    o.counters, s)
+                           : yolo_conv2d_launch(o.x, o.w, o.bias, o.residual, o.y, o.y_aux, &d, (hipStream_t)s);
         break;
       case YOLO_OP_CONV1_NCHW:
         rc = yolo_conv1_nchw_f32_fwd((const float*)o.x, d.res_c_total, o.w, o.bias, o.y, &d, s);

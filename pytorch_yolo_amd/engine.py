@@ -408,6 +408,7 @@ class Plan:
             row += na * x.h * x.w
         self.rows_total = row
         ops = []
+        splitk_ops = []                                    # (op index, workspace bytes, counters) of the split-K launches
         for nd in self.rec.nodes:
             if nd.attrs.get("fused_away"):
                 continue
@@ -510,6 +511,14 @@ class Plan:
                     assert pooled is None or op.kind == OP_CONV_POOL
                 if fused_first:
                     d.res_c_total = self.rec.c_in          # real input channels (x pointer is patched per call)
+                # split-K launches are OFF by default: correct and deterministic (tests), but on MI355X the cross-XCD exchange
+                # of the fp32 partials (agent-scope accesses that bypass the per-XCD L2) costs more than the idle CUs it
+                # fills: 0.041 -> 0.13 ms on YOLOv3-tiny's 3x3 256 -> 512 layer at 13x13 x 32
+                if op.kind == OP_CONV and os.environ.get("YOLO_SPLITK", "0") == "1":
+                    sp, wb, nc = K.conv2d_splitk_plan(d, res is not None, aux is not None)
+                    if sp >= 2:                            # few pixels, long K: split-K launch (yolo_conv2d_splitk_fwd)
+                        op.splits, op.ws_bytes = sp, wb
+                        splitk_ops.append((len(ops), wb, nc))
                 op.x = None if fused_first else x.buf.tensor.data_ptr()
                 op.w, op.bias = wp.data_ptr(), bp.data_ptr()
                 op.residual = res.buf.tensor.data_ptr() if res is not None else None
@@ -549,6 +558,11 @@ class Plan:
                 d = op.conv
                 d.n, d.h, d.w, d.cin = x.n, x.h, x.w, x.c
                 ops.append(op)
+        if splitk_ops:      # one fp32 workspace and one zeroed counter array per plan: the launches run in stream order
+            self._splitk_ws = torch.empty((max(w for _, w, _ in splitk_ops) + 3) // 4, dtype=torch.float32, device=self.device)
+            self._splitk_cnt = torch.zeros(max(c for _, _, c in splitk_ops), dtype=torch.int32, device=self.device)
+            for i, _, _ in splitk_ops:
+                ops[i].workspace, ops[i].counters = self._splitk_ws.data_ptr(), self._splitk_cnt.data_ptr()
         self.n_ops = len(ops)
         self.op_array = (YoloOp * len(ops))(*ops)
     # -- execution -----------------------------------------------------------------------------------

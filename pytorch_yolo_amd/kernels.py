@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU6, DT_BF16, DT_F32, YoloConvDesc, YoloMbconvDesc,
                    check, load)
 
-__all__ = ["stream_ptr", "pack_input", "conv2d", "stem", "resunit", "resunit_supported", "maxpool", "spp", "dwconv3x3", "mbconv", "mbconv_supported", "pack_mbconv", "conv3x3_pool", "conv3x3_pool_supported", "decode", "head_decode", "head_decode_supported",
+__all__ = ["stream_ptr", "pack_input", "conv2d", "stem", "resunit", "resunit_supported", "maxpool", "spp", "dwconv3x3", "mbconv", "mbconv_supported", "pack_mbconv", "conv3x3_pool", "conv3x3_pool_supported", "conv2d_splitk", "conv2d_splitk_plan", "decode", "head_decode", "head_decode_supported",
            "nms_merge", "pack_conv_weight", "roundup", "run_ops"]
 
 
@@ -80,6 +80,23 @@ def conv2d(x, w_packed, bias, y, desc: YoloConvDesc, residual=None, y_preadd=Non
     _need_cuda(x, w_packed, bias, y, residual, y_preadd)
     check(load().yolo_conv2d_fwd(_ptr(x), _ptr(w_packed), _ptr(bias), _ptr(residual), _ptr(y), _ptr(y_preadd),
                                  C.byref(desc), stream_ptr()), "conv2d")
+    return y
+
+
+def conv2d_splitk_plan(desc: YoloConvDesc, has_residual=False, has_preadd=False):
+    """(splits, workspace bytes, int32 counters) a layer wants for yolo_conv2d_splitk_fwd; splits == 1: it does not take it."""
+    sp, wb, nc = C.c_int(1), C.c_size_t(0), C.c_int(0)
+    check(load().yolo_conv2d_splitk_plan(C.byref(desc), int(has_residual), int(has_preadd), C.byref(sp), C.byref(wb), C.byref(nc)),
+          "conv2d_splitk_plan")
+    return sp.value, wb.value, nc.value
+
+
+def conv2d_splitk(x, w_packed, bias, y, desc: YoloConvDesc, splits, workspace, counters, residual=None, y_preadd=None):
+    """yolo_conv2d_splitk_fwd: ``workspace`` a byte / float tensor of at least the planned size, ``counters`` int32 zeros."""
+    _need_cuda(x, w_packed, bias, y, residual, y_preadd, workspace, counters)
+    check(load().yolo_conv2d_splitk_fwd(_ptr(x), _ptr(w_packed), _ptr(bias), _ptr(residual), _ptr(y), _ptr(y_preadd), C.byref(desc),
+                                        splits, _ptr(workspace), workspace.numel() * workspace.element_size(), _ptr(counters),
+                                        stream_ptr()), "conv2d_splitk")
     return y
 
 

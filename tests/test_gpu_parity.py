@@ -435,6 +435,43 @@ def test_spp_exact(h, w):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout,k,use_res", [(32, 13, 13, 256, 512, 3, False), (8, 13, 13, 1280, 64, 3, False),
+                                                      (16, 13, 13, 256, 512, 3, True), (3, 13, 13, 1280, 64, 3, False),
+                                                      (4, 26, 26, 128, 256, 3, False)])
+def test_split_k_conv(n, h, w, cin, cout, k, use_res):
+    """yolo_conv2d_splitk_fwd (layers with few pixels and a long K: several workgroups share a tile's K range, the last
+    to arrive sums the fp32 partials in split order) against fp32 torch and against the plain launch of the same layer;
+    two launches in a row must agree bit for bit (fixed summation order, self-resetting counters)."""
+    from pytorch_yolo_amd import kernels as K
+    from pytorch_yolo_amd._lib import ACT_LEAKY01
+    g = torch.Generator().manual_seed(cin + cout + n)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(n, cout, h, w, generator=g) if use_res else None
+    wp, bp, kpad, cpad = K.pack_conv_weight(wt, b, cin)
+    d = K.conv_desc(n=n, h=h, w=w, cin=cin, in_c_total=cin, in_c_offset=0, cout=cout, out_c_total=cout, out_c_offset=0,
+                    ksize=k, stride=1, act=ACT_LEAKY01, kpad=kpad, cout_pad=cpad, res=(cout, 0) if use_res else (0, 0))
+    splits, ws_bytes, n_cnt = K.conv2d_splitk_plan(d, has_residual=use_res)
+    assert splits >= 2 and ws_bytes == splits * n * h * w * cout * 4 and n_cnt > 0
+    xin, rin = _nhwc(x), (_nhwc(res) if use_res else None)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=DEV)
+    cnt = torch.zeros(n_cnt, dtype=torch.int32, device=DEV)
+    ys = [torch.empty(n, h, w, cout, dtype=torch.bfloat16, device=DEV) for _ in range(3)]
+    K.conv2d_splitk(xin, wp.to(DEV), bp.to(DEV), ys[0], d, splits, ws, cnt, residual=rin)
+    K.conv2d_splitk(xin, wp.to(DEV), bp.to(DEV), ys[1], d, splits, ws, cnt, residual=rin)
+    K.conv2d(xin, wp.to(DEV), bp.to(DEV), ys[2], d, residual=rin)
+    torch.cuda.synchronize()
+    assert int(cnt.abs().sum()) == 0                                   # counters are back at zero
+    assert torch.equal(ys[0], ys[1])                                   # deterministic
+    ref = F.leaky_relu(F.conv2d(_bf16r(x), _bf16r(wt), b, padding=k // 2), 0.1)
+    if use_res:
+        ref = ref + _bf16r(res)
+    torch.testing.assert_close(_nchw(ys[0]), ref, rtol=1e-2, atol=2e-2)
+    diff = (ys[0].float() - ys[2].float()).abs()
+    assert float(diff.max()) <= 0.07 and float((diff > 0).float().mean()) < 0.25, (float(diff.max()), float((diff > 0).float().mean()))
+
+
 @pytest.mark.parametrize("n,h,w,cin,cout,pool", [(2, 52, 52, 16, 32, True), (1, 40, 72, 32, 64, True), (2, 26, 38, 16, 64, True),
                                                  (1, 208, 208, 16, 32, True), (2, 30, 22, 32, 32, False), (1, 17, 33, 16, 32, True)])
 def test_small_cin_conv_with_maxpool(n, h, w, cin, cout, pool):

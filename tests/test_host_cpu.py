@@ -38,8 +38,8 @@ def test_struct_layout_matches_header():
     # + 2 pointers
     assert ctypes.sizeof(_lib.YoloConvDesc) == 23 * 4
     assert ctypes.sizeof(_lib.YoloMbconvDesc) == 14 * 4
-    assert ctypes.sizeof(_lib.YoloOp) == 8 + 6 * 8 + 23 * 4 + 4 + 2 * 8 + 2 * 4 + 9 * 4 + 5 * 4 + 2 * 8
-    assert _lib.YoloOp.w_pre.offset == 152 and _lib.YoloOp.kpad_pre.offset == 168 and _lib.YoloOp.w_dw.offset == 232
+    assert ctypes.sizeof(_lib.YoloOp) == 8 + 6 * 8 + 23 * 4 + 4 + 2 * 8 + 2 * 4 + 9 * 4 + 5 * 4 + 2 * 8 + 3 * 8 + 2 * 4   # + split-K fields
+    assert _lib.YoloOp.w_pre.offset == 152 and _lib.YoloOp.kpad_pre.offset == 168 and _lib.YoloOp.w_dw.offset == 232 and _lib.YoloOp.workspace.offset == 248 and _lib.YoloOp.splits.offset == 272
     mb = text_mb = open(os.path.join(ROOT, "include", "yolo_hip.h")).read()
     mb = mb[mb.index("typedef struct YoloMbconvDesc {"):mb.index("} YoloMbconvDesc;")]
     assert re.findall(r"\b([a-z_0-9]+)\s*[,;]", mb.split("{", 1)[1]) == [f for f, _ in _lib.YoloMbconvDesc._fields_]
