@@ -137,3 +137,39 @@ def scale_detections(dets, count, img1_shape, img0_shapes, round_result=True):
     check(load().yolo_scale_coords(dets.data_ptr(), dets.shape[0], dets.shape[1], dets.shape[2], params.data_ptr(),
                                    int(round_result), K.stream_ptr()), "scale_coords")
     return dets
+
+
+def _dict_from_results(data, targets, imgs_path, orig_shapes, cur_shape):
+    """Drop-in for the reference's ``_dict_from_results`` (utils.py:306-327): the detections of one batch (the list
+    ``non_max_suppression`` returns, rows x1 y1 x2 y2 conf cls_conf cls in the network frame ``cur_shape``) are mapped
+    back to each original image (``scale_coords(...).round()``, on the device, in place like the reference) and
+    appended to ``data[img_path]`` as {'type','score','left','top','right','bottom'} dicts."""
+    for i, pred in enumerate(targets):
+        if pred is None:
+            continue
+        scale_coords(cur_shape, pred, orig_shapes[i], round_result=True)
+        rows = data.setdefault(imgs_path[i], [])
+        for x1, y1, x2, y2, conf, _cls_conf, cls in pred.detach().cpu().numpy():
+            rows.append({"type": int(cls), "score": float(conf), "left": int(x1), "top": int(y1), "right": int(x2),
+                         "bottom": int(y2)})
+    return data
+
+
+def predict_dataset(model, batches, conf_thresh=0.1, nms_thresh=0.1):
+    """The loop of the reference's ``test_model`` (utils.py:357-378) up to its prediction dictionary: for every
+    ``(imgs, targets, imgs_path, shapes)`` batch (the reference dataset's collate format; ``targets`` is ignored):
+    forward, NMS, back-projection.  The COCO scoring that follows in the reference (``coco_helper`` + pycocotools,
+    utils.py:380-393) is outside this path and not installed here."""
+    was_training = model.training
+    model.eval()
+    data = {}
+    try:
+        for imgs, _targets, imgs_path, shapes in batches:
+            imgs = imgs.to(next(model.parameters()).device)
+            with torch.no_grad():
+                det = model.detect(imgs, conf_thresh, nms_thresh)
+            _dict_from_results(data, det, imgs_path, shapes, tuple(imgs.shape[-2:]))
+    finally:
+        if was_training:
+            model.train()
+    return data

@@ -115,3 +115,19 @@ def scale_coords_boxes(n: int = 200, seed: int = 41) -> np.ndarray:
     b = rng.uniform(-20, 660, (n, 4)).astype(np.float32)
     b[:, 2:] = b[:, :2] + rng.uniform(1, 300, (n, 2)).astype(np.float32)
     return b
+
+
+def results_case(seed: int = 43):
+    """Input of the reference's ``_dict_from_results`` (utils/utils.py:306-327): three images, the middle one without
+    detections; rows (x1, y1, x2, y2, conf, cls_conf, cls) in a 416 x 416 network frame."""
+    rng = np.random.default_rng(seed)
+    dets = []
+    for n in (7, 0, 12):
+        if n == 0:
+            dets.append(None)
+            continue
+        b = rng.uniform(-10, 400, (n, 4)).astype(np.float32)
+        b[:, 2:] = b[:, :2] + rng.uniform(2, 200, (n, 2)).astype(np.float32)
+        rest = np.stack([rng.uniform(0.1, 1, n), rng.uniform(0.1, 1, n), rng.integers(0, 80, n)], 1).astype(np.float32)
+        dets.append(np.concatenate([b, rest], 1))
+    return dets, ["a.jpg", "b.jpg", "a.jpg"], [(480, 640), (375, 500), (1080, 1920)], (416, 416)
