@@ -22,7 +22,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from pytorch_yolo_amd import YOLOv3SPP, YOLOv3Tiny, YOLOv3TinyMobile, YOLOv3TinySqueeze          # noqa: E402
+from pytorch_yolo_amd import YOLOv3SPP, YOLOv3Tiny, YOLOv3TinyMobile, YOLOv3TinyShuffle, YOLOv3TinySqueeze          # noqa: E402
 from pytorch_yolo_amd.distributed import PipelinedGather                    # noqa: E402
 from pytorch_yolo_amd.utils.synthetic import synth_images, synth_state_dict  # noqa: E402
 from pytorch_yolo_amd.utils.utils import nms_capacity, nms_raw               # noqa: E402
@@ -42,6 +42,8 @@ WORKLOADS = {
                    name="YOLOv3-tiny MobileNetV2 416x416 bs=64/GPU detect()"),
     "squeeze": dict(cls=YOLOv3TinySqueeze, kw=dict(), hw=416, bs=32,
                     name="YOLOv3-tiny SqueezeNet 1.1 416x416 bs=32/GPU detect()"),
+    "shuffle": dict(cls=YOLOv3TinyShuffle, kw=dict(), hw=416, bs=32,
+                    name="YOLOv3-tiny ShuffleNetV2 x1.0 416x416 bs=32/GPU detect()"),
 }
 CONF_THRES, NMS_THRES = 0.1, 0.5
 
@@ -73,7 +75,8 @@ def cpu_baseline(workload: str, seconds_budget: float = 20.0):
         tmpl = YOLOv3SPP(anchors=SPP_ANCHORS).state_dict()
     else:
         fwd, cls = {"tiny": (om.tiny_forward, YOLOv3Tiny), "mobile": (om.tiny_mobile_forward, YOLOv3TinyMobile),
-                    "squeeze": (om.tiny_squeeze_forward, YOLOv3TinySqueeze)}[workload]
+                    "squeeze": (om.tiny_squeeze_forward, YOLOv3TinySqueeze),
+                    "shuffle": (om.tiny_shuffle_forward, YOLOv3TinyShuffle)}[workload]
         anchors, hw = om.TINY_ANCHORS, 416
         tmpl = cls().state_dict()
     cores = host_cores()

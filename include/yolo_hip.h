@@ -120,6 +120,14 @@ YOLO_API int yolo_dwconv3x3_fwd(const void* x, const float* w, const float* bias
                        int c, int in_c_total, int in_c_offset, int ho, int wo, int out_c_total,
                        int out_c_offset, int stride, int act, yolo_stream_t s);
 
+/* ---- ShuffleNetV2's channel_shuffle(cat(a, b), groups = 2) (torchvision shufflenetv2, used by
+ *  models/yolov3_tiny_shuffle.py:13-47): a and b are bf16 NHWC views holding `half` logical channels each in slots of
+ *  c_slot physical channels (zero beyond `half`); y gets logical channel j = (a, b)[j % 2][j / 2] in the same two-slot
+ *  layout: logical [0, half) at [0, ...), logical [half, 2 half) at [c_slot, ...); its pad channels are left alone. */
+YOLO_API int yolo_channel_shuffle2_fwd(const void* a, const void* b, void* y, int n, int h, int w, int half, int c_slot,
+                                       int a_c_total, int a_c_offset, int b_c_total, int b_c_offset, int y_c_total,
+                                       int y_c_offset, yolo_stream_t s);
+
 /* ---- MaxPool (models/yolo_base.py:60-66): -inf padding; the (2,1) special is pad 1, dilation 2. */
 YOLO_API int yolo_maxpool_fwd(const void* x, void* y, int n, int h, int w, int c, int in_c_total, int in_c_offset,
                      int ho, int wo, int out_c_total, int out_c_offset, int ksize, int stride, int pad,
@@ -220,7 +228,8 @@ YOLO_API int yolo_letterbox_u8_fwd(const uint8_t* src, int h, int w, int c, int 
 /* ---- batched launcher: run a recorded list of ops with one FFI crossing (host overhead only). */
 enum { YOLO_OP_CONV = 1, YOLO_OP_MAXPOOL = 2, YOLO_OP_SPP = 3, YOLO_OP_DWCONV = 4, YOLO_OP_CONV1_NCHW = 5,
        YOLO_OP_RESUNIT = 6, YOLO_OP_STEM = 7, YOLO_OP_HEAD_DECODE = 8, YOLO_OP_CONV1_POOL = 9, YOLO_OP_MBCONV = 10,
-       YOLO_OP_CONV_POOL = 11 /* yolo_conv3x3_pool_fwd with pool = 1: x = bf16 NHWC, y = the pooled map */ };
+       YOLO_OP_CONV_POOL = 11 /* yolo_conv3x3_pool_fwd with pool = 1: x = bf16 NHWC, y = the pooled map */,
+       YOLO_OP_SHUFFLE = 12 /* yolo_channel_shuffle2_fwd: x = a, residual = b, conv.cin = c_slot, conv.cout = half, res_* = view of b */ };
 typedef struct YoloOp {
   int32_t kind, _pad;
   const void* x; const void* w; const float* bias; const void* residual; void* y; void* y_aux;

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("YOLO_HIP_LIB") or os.path.join(_HERE, "csrc", "libyol
 ACT_NONE, ACT_LEAKY01, ACT_RELU6, ACT_RELU = 0, 1, 2, 3
 DT_BF16, DT_F32 = 0, 1
 OP_CONV, OP_MAXPOOL, OP_SPP, OP_DWCONV, OP_CONV1_NCHW, OP_RESUNIT, OP_STEM, OP_HEAD_DECODE, OP_CONV1_POOL = 1, 2, 3, 4, 5, 6, 7, 8, 9
-OP_MBCONV, OP_CONV_POOL = 10, 11
+OP_MBCONV, OP_CONV_POOL, OP_SHUFFLE = 10, 11, 12
 
 
 class YoloConvDesc(C.Structure):
@@ -71,6 +71,7 @@ SIGNATURES = {
     "yolo_mbconv_supported": (C.c_int, [C.c_int] * 4),
     "yolo_mbconv_fwd": (C.c_int, [C.c_void_p] * 8 + [C.POINTER(YoloMbconvDesc), C.c_void_p]),
     "yolo_dwconv3x3_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 12 + [C.c_void_p]),
+    "yolo_channel_shuffle2_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 11 + [C.c_void_p]),
     "yolo_maxpool_fwd": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 14 + [C.c_void_p]),
     "yolo_spp_fwd": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
     "yolo_decode_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 5 + [C.c_float, C.c_void_p,

@@ -237,6 +237,41 @@ extern "C" int yolo_maxpool_fwd(const void* x, void* y, int n, int h, int w, int
   return yolo_check_launch("yolo_maxpool_fwd");
 }
 
+// channel_shuffle(cat(a, b), 2) in the two-slot layout (see include/yolo_hip.h): thread = 8 physical output channels of a pixel
+__global__ __launch_bounds__(256) void shuffle2_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                       bf16_t* __restrict__ y, int half, int c_slot, int a_ct, int a_co, int b_ct,
+                                                       int b_co, int y_ct, int y_co, long total) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int groups = 2 * c_slot / 8;
+  const int g = (int)(t % groups);
+  const long pix = t / groups;
+  const bf16_t* const pa = a + pix * a_ct + a_co;
+  const bf16_t* const pb = b + pix * b_ct + b_co;
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int pc = g * 8 + e, slot = pc / c_slot, r = pc - slot * c_slot;
+    const int j = slot * half + r;                    // logical output channel
+    o[e] = r < half ? ((j & 1) ? pb[j >> 1] : pa[j >> 1]) : (bf16_t)0.f;
+  }
+  *reinterpret_cast<bf16x8*>(y + pix * y_ct + y_co + g * 8) = o;
+}
+
+extern "C" int yolo_channel_shuffle2_fwd(const void* a, const void* b, void* y, int n, int h, int w, int half, int c_slot,
+                                         int a_c_total, int a_c_offset, int b_c_total, int b_c_offset, int y_c_total,
+                                         int y_c_offset, yolo_stream_t s) {
+  YOLO_REQUIRE(a && b && y && n > 0 && h > 0 && w > 0, "shuffle2: bad arguments");
+  YOLO_REQUIRE(half >= 1 && half <= c_slot && c_slot % 8 == 0, "shuffle2: %d logical channels per slot of %d", half, c_slot);
+  YOLO_REQUIRE(a_c_offset + c_slot <= a_c_total && b_c_offset + c_slot <= b_c_total && y_c_offset + 2 * c_slot <= y_c_total &&
+                   y_c_offset % 8 == 0 && y_c_total % 8 == 0,
+               "shuffle2: bad views");
+  const long total = (long)n * h * w * (2 * c_slot / 8);
+  hipLaunchKernelGGL(shuffle2_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)a, (const bf16_t*)b,
+                     (bf16_t*)y, half, c_slot, a_c_total, a_c_offset, b_c_total, b_c_offset, y_c_total, y_c_offset, total);
+  return yolo_check_launch("yolo_channel_shuffle2_fwd");
+}
+
 extern "C" int yolo_spp_fwd(void* buf, int n, int h, int w, int c, yolo_stream_t s) {
   YOLO_REQUIRE(buf && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0, "spp: bad arguments");
   const size_t lds = (size_t)4 * h * w * 16;

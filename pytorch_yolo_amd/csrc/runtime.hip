@@ -55,6 +55,10 @@ extern "C" int yolo_run_ops(const YoloOp* ops, int n_ops, yolo_stream_t s) {
         rc = yolo_head_decode_fwd(o.x, o.w, o.bias, &d, o.head_anchors_px, o.head_na, o.head_nc, o.head_stride_px, (float*)o.y,
                                   o.io_rows_total, o.io_row_offset, (float*)o.y_aux, s);
         break;
+      case YOLO_OP_SHUFFLE:
+        rc = yolo_channel_shuffle2_fwd(o.x, o.residual, o.y, d.n, d.h, d.w, d.cout, d.cin, d.in_c_total, d.in_c_offset, d.res_c_total,
+                                       d.res_c_offset, d.out_c_total, d.out_c_offset, s);
+        break;
       case YOLO_OP_CONV_POOL:
         rc = yolo_conv3x3_pool_fwd(o.x, o.w, o.bias, o.y, &d, 1, s);
         break;

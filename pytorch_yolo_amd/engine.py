@@ -28,7 +28,7 @@ import torch
 
 from . import kernels as K
 from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU, ACT_RELU6, DT_BF16, DT_F32, OP_CONV, OP_CONV1_NCHW, OP_DWCONV,
-                   OP_CONV1_POOL, OP_CONV_POOL, OP_MBCONV, OP_HEAD_DECODE, OP_MAXPOOL, OP_RESUNIT, OP_SPP, OP_STEM, YoloOp)
+                   OP_CONV1_POOL, OP_CONV_POOL, OP_MBCONV, OP_SHUFFLE, OP_HEAD_DECODE, OP_MAXPOOL, OP_RESUNIT, OP_SPP, OP_STEM, YoloOp)
 
 # which residual-unit widths run as ONE launch (bit mask of C: 64 | 128 | 256); see DESIGN.md §3.1d for the
 # measurements behind the default.  YOLO_FUSE_RESUNIT overrides it (tuning only).
@@ -146,6 +146,25 @@ class Recorder:
     def concat(self, xs: List[Sym]):
         y = Sym(xs[0].n, xs[0].h, xs[0].w, sum(x.c for x in xs))
         self._add("cat", xs, [y])
+        return y
+
+    def slice(self, x: Sym, offset: int, c: int):
+        """Channel view [offset, offset + c) of ``x`` (8-channel aligned): no launch, the consumers read the view."""
+        if offset % 8 or c % 8 or offset + c > x.c:
+            raise RuntimeError("slice: views are 8-channel aligned")
+        y = Sym(x.n, x.h, x.w, c)
+        self._add("slice", [x], [y], offset=offset)
+        return y
+
+    def shuffle2(self, a: Sym, b: Sym, half: int):
+        """ShuffleNetV2's ``channel_shuffle(cat(a, b), groups=2)`` for two tensors of ``half`` logical channels each,
+        every one held in a slot of a.c == b.c >= half physical channels (zero beyond ``half``): logical channel j of the
+        result is (a, b)[j % 2][j // 2]; the result keeps the two-slot layout (logical [0, half) in slot 0, [half, 2 half)
+        in slot 1)."""
+        if a.c != b.c or half > a.c or (a.h, a.w) != (b.h, b.w):
+            raise RuntimeError("shuffle2: mismatched halves")
+        y = Sym(a.n, a.h, a.w, 2 * a.c)
+        self._add("shuffle", [a, b], [y], half=half)
         return y
 
     def head(self, x: Sym, yolo_layer):
@@ -298,6 +317,8 @@ class Plan:
         for nd in nodes:
             if nd.attrs.get("fused_away") or nd.attrs.get("head_fused"):
                 continue
+            if nd.kind == "slice":
+                continue                                   # a view: resolved below
             for o in nd.outs:
                 if nd.kind == "conv" and nd.attrs.get("small_pool"):
                     pooled = nd.attrs["pool_into"]         # the full-resolution map is never materialised, the pooled one is
@@ -308,6 +329,10 @@ class Plan:
                     if nd.kind == "conv" and nd.attrs.get("alias_res") and o.slot == 0:
                         continue
                     o.buf, o.c_offset = self._new_buf(o), 0
+        for nd in nodes:      # channel views (in node order: a view of a view resolves too)
+            if nd.kind == "slice":
+                src, y = nd.srcs[0], nd.outs[0]
+                y.buf, y.c_offset = src.buf, src.c_offset + nd.attrs["offset"]
         for nd in nodes:      # resolve in-place aliases now that the residual inputs have buffers
             if nd.kind == "conv" and nd.attrs.get("alias_res"):
                 res, y = nd.srcs[1], nd.outs[0]
@@ -538,6 +563,17 @@ class Plan:
                 d.n, d.h, d.w, d.cin = x.n, x.h, x.w, x.c
                 d.in_c_total, d.in_c_offset, d.ho, d.wo = x.buf.c_total, x.c_offset, y.h, y.w
                 d.out_c_total, d.out_c_offset, d.stride, d.act = y.buf.c_total, y.c_offset, nd.attrs["stride"], _ACT[nd.attrs["act"]]
+                ops.append(op)
+            elif nd.kind == "shuffle":
+                a_, b_, y = nd.srcs[0], nd.srcs[1], nd.outs[0]
+                op = YoloOp()
+                op.kind = OP_SHUFFLE
+                op.x, op.residual, op.y = a_.buf.tensor.data_ptr(), b_.buf.tensor.data_ptr(), y.buf.tensor.data_ptr()
+                d = op.conv
+                d.n, d.h, d.w, d.cin = a_.n, a_.h, a_.w, a_.c            # cin = physical channels per slot
+                d.in_c_total, d.in_c_offset = a_.buf.c_total, a_.c_offset
+                d.res_c_total, d.res_c_offset = b_.buf.c_total, b_.c_offset
+                d.out_c_total, d.out_c_offset, d.cout = y.buf.c_total, y.c_offset, nd.attrs["half"]   # cout = logical half
                 ops.append(op)
             elif nd.kind == "pool":
                 x, y = nd.srcs[0], nd.outs[0]

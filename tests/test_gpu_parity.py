@@ -655,13 +655,13 @@ def _model_errors(io, io_ref):
     return box.max().item(), box_rel.max().item(), score.max().item()
 
 
-def _assert_model_close(io, io_ref, tag, score_max=2e-2, score_rms=2e-3):
+def _assert_model_close(io, io_ref, tag, score_max=2e-2, score_rms=2e-3, box_rel_tol=0.02):
     box_abs, box_rel, score = _model_errors(io, io_ref)
     rms = (io[..., 4:].double() - io_ref[..., 4:].double()).pow(2).mean().sqrt().item()
     print(f"[{tag}] bf16-vs-fp32: max box abs {box_abs:.4f} px, max box rel {box_rel:.4f}, "
           f"max score abs {score:.5f}, rms score {rms:.6f}")
-    ok_box = ((io[..., :4] - io_ref[..., :4]).abs() <= torch.maximum(torch.tensor(1.5), 0.02 * io_ref[..., :4].abs())).all()
-    assert ok_box, f"{tag}: boxes outside max(1.5 px, 2 %)"
+    ok_box = ((io[..., :4] - io_ref[..., :4]).abs() <= torch.maximum(torch.tensor(1.5), box_rel_tol * io_ref[..., :4].abs())).all()
+    assert ok_box, f"{tag}: boxes outside max(1.5 px, {100 * box_rel_tol:.0f} %)"
     assert score <= score_max, f"{tag}: scores differ by {score}"
     assert rms <= score_rms, f"{tag}: rms score error {rms}"
 
@@ -723,6 +723,91 @@ def test_squeezenet_variant_vs_oracle(n, h, w):
         io, p = model.to(DEV)(x.to(DEV))
     assert io.shape == io_ref.shape and [tuple(q.shape) for q in p] == [tuple(q.shape) for q in p_ref]
     _assert_model_close(io.cpu(), io_ref, f"squeeze_{h}x{w}", score_max=3e-2, score_rms=4e-3)
+
+
+def test_channel_shuffle_kernel_exact():
+    """yolo_channel_shuffle2_fwd against torch's view / transpose / reshape channel shuffle of cat(a, b), for halves
+    that do not fill their 8-channel-aligned slots (58 in 64, 116 in 120) and for views into wider buffers."""
+    from pytorch_yolo_amd import engine
+    for half, slot in ((58, 64), (116, 120), (232, 232), (8, 8)):
+        g = torch.Generator().manual_seed(half)
+        x = _bf16r(torch.randn(2, 2 * slot, 9, 7, generator=g))
+        x[:, half:slot] = 0
+        x[:, slot + half:] = 0                                  # the pad channels of both slots are zero by contract
+
+        def trace(rec, s):
+            return rec.shuffle2(rec.slice(s, 0, slot), rec.slice(s, slot, slot), half)
+        got = engine.run_standalone(trace, x.to(DEV)).cpu()
+        logical = torch.cat([x[:, :half], x[:, slot:slot + half]], 1)
+        want = logical.view(2, 2, half, 9, 7).transpose(1, 2).reshape(2, 2 * half, 9, 7)
+        assert torch.equal(got[:, :half], want[:, :half]) and torch.equal(got[:, slot:slot + half], want[:, half:])
+        assert float(got[:, half:slot].abs().sum()) == 0 and float(got[:, slot + half:].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 96, 128), (1, 416, 416)])
+def test_shufflenet_variant_vs_oracle(n, h, w):
+    """YOLOv3TinyShuffle: ShuffleNetV2 x1.0 traced in a padded physical channel space (halves of 58 /
+    116 channels in 64- / 120-channel slots), channel split as views, channel shuffle as one copy kernel, linear
+    depthwise convs.  The encoder oracle restates the published network (torchvision absent: parity unpinned,
+    oracle/shufflenet.py)."""
+    from oracle import models as om
+    from pytorch_yolo_amd import YOLOv3TinyShuffle
+    from pytorch_yolo_amd.utils.synthetic import synth_images, synth_state_dict
+    model = YOLOv3TinyShuffle(n_class=3).eval()
+    sd = synth_state_dict(model.state_dict(), 5, n_class=3)
+    model.load_state_dict(sd)
+    x = synth_images(n, h, w, 3)
+    with torch.no_grad():
+        io_ref, p_ref = om.tiny_shuffle_forward(sd, x, om.TINY_ANCHORS, 3)
+        io, p = model.to(DEV)(x.to(DEV))
+    assert io.shape == io_ref.shape and [tuple(q.shape) for q in p] == [tuple(q.shape) for q in p_ref]
+    # 16 units without any normalising residual: with the synthetic BN gains the activations grow to |x| ~ 60 and the bf16
+    # drift to ~1.2 % rms by the last unit (test_shufflenet_units_track_the_oracle shows it grow smoothly, unit by unit);
+    # the heads turn that into up to 0.09 on a sigmoid and up to 16 % on exp(tw) - hence the wider bounds than for the other models
+    _assert_model_close(io.cpu(), io_ref, f"shuffle_{h}x{w}", score_max=0.12, score_rms=1.2e-2, box_rel_tol=0.25)
+
+
+def test_shufflenet_units_track_the_oracle():
+    """Every one of the 16 ShuffleNetV2 units against the oracle's unit on the same input image: the physical (padded,
+    two-slot) tensor mapped back to logical channels stays within 3 % of the oracle's dynamic range and 2 % relative rms,
+    drifting smoothly (a mis-wired channel map or shuffle would be an O(1) error from that unit on)."""
+    import torch.nn.functional as F2
+    from oracle.shufflenet import _bn, _unit
+    from pytorch_yolo_amd import YOLOv3TinyShuffle, engine
+    from pytorch_yolo_amd.models.yolov3_tiny_shuffle import _folded
+    from pytorch_yolo_amd.utils.synthetic import synth_images, synth_state_dict
+    model = YOLOv3TinyShuffle(n_class=3).eval()
+    sd = synth_state_dict(model.state_dict(), 5, n_class=3)
+    model.load_state_dict(sd)
+    enc, x, maps = model.features, synth_images(2, 96, 128, 3), []
+
+    def trace(g, s):
+        c1 = enc.sequence1[0]
+        t = g.maxpool(g.conv(s, _folded(c1[0], c1[1]), stride=2, act="relu"), 3, 2)
+        res, cmap = [t], list(range(24))
+        maps.append(cmap)
+        for stage in (enc.sequence1[2], enc.sequence1[3], enc.sequence2[0]):
+            for unit in stage:
+                t, cmap = unit._trace(g, t, cmap)
+                res.append(t)
+                maps.append(cmap)
+        return res
+    got = engine.run_standalone(trace, x.to(DEV))
+    p = "features.sequence1"
+    r = F2.max_pool2d(F2.relu(_bn(sd, p + ".0.1", F2.conv2d(x, sd[p + ".0.0.weight"], None, stride=2, padding=1))), 3, 2, 1)
+    refs = [r]
+    for name, rep in ((p + ".2", 4), (p + ".3", 8), ("features.sequence2.0", 4)):
+        for u in range(rep):
+            r = _unit(sd, f"{name}.{u}", r, 2 if u == 0 else 1)
+            refs.append(r)
+    assert len(got) == len(refs) == 17
+    for i, (g_, r_, mp) in enumerate(zip(got, refs, maps)):
+        gl = g_.cpu()
+        pad = [c for c in range(gl.shape[1]) if c not in set(mp)]
+        assert float(gl[:, pad].abs().sum()) == 0, f"unit {i}: pad channels are not zero"
+        err = (gl[:, mp] - r_).abs()
+        assert float(err.max()) <= 0.03 * float(r_.abs().max()), (i, float(err.max()), float(r_.abs().max()))
+        assert float(err.pow(2).mean().sqrt() / r_.pow(2).mean().sqrt()) <= 0.02, i
 
 
 def test_mobilenet_fused_blocks_match_three_launch_path(monkeypatch):

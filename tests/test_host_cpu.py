@@ -193,6 +193,28 @@ def test_planner_squeezenet_variant():
     assert plan.rows_total == 2 * 3 * 25 * 25 and [h["stride"] for h in plan.heads] == [416 / 25, 416 / 25]
 
 
+def test_planner_shufflenet_variant():
+    """YOLOv3TinyShuffle (reference models/yolov3_tiny_shuffle.py): torchvision's ShuffleNetV2 x1.0 key names; on the
+    device the halves of 58 / 116 channels sit in 64- / 120-channel slots, x.chunk(2) is two views and every unit ends
+    in one channel-shuffle copy."""
+    from pytorch_yolo_amd import YOLOv3TinyShuffle
+    from pytorch_yolo_amd._lib import OP_SHUFFLE
+    m = YOLOv3TinyShuffle().eval()
+    sd = m.state_dict()
+    assert sd["features.sequence1.0.0.weight"].shape == (24, 3, 3, 3) and sd["features.sequence1.2.0.branch1.2.weight"].shape == (58, 24, 1, 1)
+    assert sd["features.sequence1.3.5.branch2.3.weight"].shape == (116, 1, 3, 3) and sd["features.sequence2.1.0.weight"].shape == (1024, 464, 1, 1)
+    assert sd["sequence_branch1_2.branch1_conv2.sequence.conv.weight"].shape == (128, 232 + 128, 3, 3)
+    plan = _dry_plan(m, 416)
+    ops = _ops(plan)
+    kinds = [o.kind for o in ops]
+    assert kinds.count(OP_SHUFFLE) == 16 and kinds.count(OP_DWCONV) == 19 and kinds.count(OP_HEAD_DECODE) == 2
+    sh = [o.conv for o in ops if o.kind == OP_SHUFFLE]
+    assert [(c.cin, c.cout) for c in sh] == [(64, 58)] * 4 + [(120, 116)] * 8 + [(232, 232)] * 4        # (slot, logical half)
+    assert (sh[1].in_c_total, sh[1].in_c_offset, sh[1].res_c_total) == (128, 0, 64)      # x1 = slot 0 of the previous unit, b = branch2
+    assert sh[11].out_c_total == 240 + 128                           # route1 is shuffled straight into the head's concat buffer
+    assert plan.rows_total == 3 * (26 * 26 + 13 * 13)
+
+
 def test_unsupported_widths_fail_loudly():
     m = YOLOv3SPP(anchors=C.SPP_ANCHORS, kernels_divider=8).eval()
     with pytest.raises(RuntimeError, match="multiple of 8"):
