@@ -10,7 +10,8 @@ reference (:28-35, :58-69).
 
 On the device the stage widths 116 / 232 / 464 split into halves of 58 / 116 / 232 channels, and 58 and 116 are not
 multiples of the 8-channel (16-byte) granule of the NHWC views.  The trace therefore runs in a padded physical space:
-a unit's output keeps its two halves in two slots of 64 / 120 / 232 physical channels; the weights recorded for every
+a unit's output keeps its two halves in two slots of 64 / 128 / 256 physical channels (multiples of 32, which also
+keeps every conv on the fast LDS-DMA path); the weights recorded for every
 conv are the logical ones scattered into that space (zero rows, columns and biases for the pad channels, which ReLU
 and the linear depthwise stage keep at zero), the stride-1 split ``x.chunk(2)`` is two channel views, and
 ``channel_shuffle(cat(a, b), 2)`` is one copy kernel (``yolo_channel_shuffle2_fwd``).
@@ -28,6 +29,7 @@ from .yolo_layer import Concat, Upsample
 from .yolov3_tiny import plain_head
 
 _STAGES = ((4, 116), (8, 232), (4, 464))
+_SLOT = 32      # slot granule: 8 channels would do for the views; 32 keeps every 1x1 / 3x3 conv on the LDS-DMA fast path
 
 
 def _folded(conv: nn.Conv2d, bn: nn.BatchNorm2d):
@@ -85,7 +87,7 @@ class InvertedResidual(nn.Module):
 
     def _trace(self, g, x, in_map):
         """x: the physical tensor, in_map[i] = physical channel of logical input channel i.  Returns (y, map of y)."""
-        h, hp = self.bf, roundup(self.bf, 8)
+        h, hp = self.bf, roundup(self.bf, _SLOT)
         rows = list(range(h))
         if self.stride > 1:
             b1 = self.branch1
@@ -118,9 +120,10 @@ class ShuffleEncoder(nn.Module):
     def _trace(self, g, x):
         """Returns (route1 physical tensor, its channel map, route2)."""
         c1 = self.sequence1[0]
-        x = g.conv(x, _folded(c1[0], c1[1]), stride=2, act="relu")
-        x = g.maxpool(x, 3, 2)
         cmap = list(range(24))
+        x = g.conv(x, _scatter(_folded(c1[0], c1[1]), cmap, roundup(24, _SLOT), list(range(c1[0].in_channels)), c1[0].in_channels),
+                   stride=2, act="relu")                       # 24 real channels in a 32-channel tensor
+        x = g.maxpool(x, 3, 2)
         for stage in (self.sequence1[2], self.sequence1[3]):
             for unit in stage:
                 x, cmap = unit._trace(g, x, cmap)

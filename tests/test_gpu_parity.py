@@ -747,7 +747,7 @@ def test_channel_shuffle_kernel_exact():
 @pytest.mark.parametrize("n,h,w", [(2, 96, 128), (1, 416, 416)])
 def test_shufflenet_variant_vs_oracle(n, h, w):
     """YOLOv3TinyShuffle: ShuffleNetV2 x1.0 traced in a padded physical channel space (halves of 58 /
-    116 channels in 64- / 120-channel slots), channel split as views, channel shuffle as one copy kernel, linear
+    116 / 232 channels in 64- / 128- / 256-channel slots), channel split as views, channel shuffle as one copy kernel, linear
     depthwise convs.  The encoder oracle restates the published network (torchvision absent: parity unpinned,
     oracle/shufflenet.py)."""
     from oracle import models as om

@@ -195,7 +195,7 @@ def test_planner_squeezenet_variant():
 
 def test_planner_shufflenet_variant():
     """YOLOv3TinyShuffle (reference models/yolov3_tiny_shuffle.py): torchvision's ShuffleNetV2 x1.0 key names; on the
-    device the halves of 58 / 116 channels sit in 64- / 120-channel slots, x.chunk(2) is two views and every unit ends
+    device the halves of 58 / 116 / 232 channels sit in 64- / 128- / 256-channel slots, x.chunk(2) is two views and every unit ends
     in one channel-shuffle copy."""
     from pytorch_yolo_amd import YOLOv3TinyShuffle
     from pytorch_yolo_amd._lib import OP_SHUFFLE
@@ -209,9 +209,9 @@ def test_planner_shufflenet_variant():
     kinds = [o.kind for o in ops]
     assert kinds.count(OP_SHUFFLE) == 16 and kinds.count(OP_DWCONV) == 19 and kinds.count(OP_HEAD_DECODE) == 2
     sh = [o.conv for o in ops if o.kind == OP_SHUFFLE]
-    assert [(c.cin, c.cout) for c in sh] == [(64, 58)] * 4 + [(120, 116)] * 8 + [(232, 232)] * 4        # (slot, logical half)
+    assert [(c.cin, c.cout) for c in sh] == [(64, 58)] * 4 + [(128, 116)] * 8 + [(256, 232)] * 4        # (slot, logical half)
     assert (sh[1].in_c_total, sh[1].in_c_offset, sh[1].res_c_total) == (128, 0, 64)      # x1 = slot 0 of the previous unit, b = branch2
-    assert sh[11].out_c_total == 240 + 128                           # route1 is shuffled straight into the head's concat buffer
+    assert sh[11].out_c_total == 256 + 128                           # route1 is shuffled straight into the head's concat buffer
     assert plan.rows_total == 3 * (26 * 26 + 13 * 13)
 
 
