@@ -55,8 +55,16 @@ class Fire(nn.Module):
         self.expand3x3_activation = nn.ReLU(inplace=True)
 
     def _trace(self, g, x):
-        s = g.conv(x, _wb(self.squeeze), act="relu")
-        return g.concat([g.conv(s, _wb(self.expand1x1), act="relu"), g.conv(s, _wb(self.expand3x3), act="relu")])
+        # the squeeze tensor (16 / 32 / 48 / 64 channels) is kept in a multiple of 32 physical channels (zero weight rows
+        # and biases, zero input columns in the expand convs): the expand convs then take the LDS-DMA fast path
+        sq, sp = self.squeeze.out_channels, -(-self.squeeze.out_channels // 32) * 32
+        w, b = _wb(self.squeeze)
+        s = g.conv(x, (torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, sp - sq)), torch.nn.functional.pad(b, (0, sp - sq))), act="relu")
+
+        def widen(conv):
+            w_, b_ = _wb(conv)
+            return torch.nn.functional.pad(w_, (0, 0, 0, 0, 0, sp - sq)), b_
+        return g.concat([g.conv(s, widen(self.expand1x1), act="relu"), g.conv(s, widen(self.expand3x3), act="relu")])
 
 
 def _squeezenet1_1_features(in_channels):

@@ -188,7 +188,7 @@ def test_planner_squeezenet_variant():
     convs = [o for o in ops if o.kind == OP_CONV]
     # 1 stem + 8 fires x 3 convs + 3 ConvBlocks of the head; the two heads decode in their conv epilogue
     assert len(convs) == 1 + 24 + 3 and sum(1 for o in ops if o.kind == OP_HEAD_DECODE) == 2
-    fire_out = [(o.conv.out_c_total, o.conv.out_c_offset) for o in convs if o.conv.cin == 16 and o.conv.h == 103][:2]
+    fire_out = [(o.conv.out_c_total, o.conv.out_c_offset) for o in convs if o.conv.cin == 32 and o.conv.h == 103][:2]   # squeeze 16 -> 32 physical
     assert fire_out == [(128, 0), (128, 64)]                       # expand1x1 | expand3x3 share the concat buffer
     assert plan.rows_total == 2 * 3 * 25 * 25 and [h["stride"] for h in plan.heads] == [416 / 25, 416 / 25]
 
