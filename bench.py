@@ -3,16 +3,21 @@
 640x640 batches, YOLOv3-SPP, bs=32 per MI355X (BASELINE.json).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...          # starts N ranks itself (one child process per GPU under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the whole hot path over one batch of 32 images per GPU (inputs already
 resident in HBM).  For N>1 every rank runs its own 32 images (weak scaling) and the per-rank
 detections are all-gathered (RCCL) inside the timed step.  Rank 0 prints ONE JSON line.
+`--gpus N` with fewer than N visible GPUs, or a WORLD_SIZE that disagrees with N, exits non-zero: a run never reports
+fewer ranks than it was asked for.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -99,6 +104,91 @@ def cpu_baseline(workload: str, seconds_budget: float = 20.0):
                 sample=f"oracle fp32 torch forward + numpy MERGE-NMS, {iters} x bs={bs} {hw}x{hw}, {dt:.1f} s")
 
 
+def _free_port() -> int:
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(args, argv) -> int:
+    """`python bench.py --gpus N` outside torch.distributed.run: start N fresh rank processes (one per GPU) and relay rank 0's
+    JSON line.  This parent never initialises the GPU (torch.cuda.device_count() does not) and never re-execs."""
+    dry = args.dry_run
+    if not dry:
+        visible = torch.cuda.device_count()
+        if visible < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} requested but only {visible} GPU(s) are visible; refusing to report a "
+                  f"{args.gpus}-GPU number from fewer ranks", file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, world, rank):
+    """Launcher / collective rehearsal without a GPU (tests/test_distributed_cpu.py): N ranks over gloo exchange detection
+    buffers of the real shapes through the same gather and print the JSON line with value null.  Nothing is measured."""
+    from pytorch_yolo_amd.distributed import gather_detections
+    dist.init_process_group("gloo")
+    bs, cap = 4, 64
+    dets = torch.full((bs, cap, 7), float(rank), dtype=torch.float32)
+    count = torch.full((bs,), rank + 1, dtype=torch.int32)
+    for _ in range(args.warmup + args.steps):
+        all_dets, all_count = gather_detections(dets, count)
+    dist.barrier()
+    ok = all_count.tolist() == [r + 1 for r in range(world) for _ in range(bs)] and all_dets.shape[0] == world * bs
+    if rank == 0:
+        print(json.dumps({"metric": "images/sec YOLOv3-SPP 640x640 bs=32 detect()", "value": None, "unit": "images/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+                          "data": "dry-run: no GPU, launcher + gloo all-gather rehearsal only (nothing measured)",
+                          "config": {"workload": "dry-run", "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                                     "gather_ok": bool(ok)}}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def solo_kernel_table(plan0, repeat=5):
+    """Every launch of ONE sub-batch list timed alone (HIP events on the launch stream, median of ``repeat``), grouped by
+    what it computes; returns the groups sorted by total time.  'Solo' = nothing else on the chip: the concurrent-stream
+    step time is NOT the sum of these."""
+    import ctypes as C
+    import statistics
+    from pytorch_yolo_amd._lib import (OP_CONV, OP_CONV1_NCHW, OP_CONV1_POOL, OP_CONV_POOL, OP_HEAD_DECODE, OP_RESUNIT, OP_STEM,
+                                       YoloOp)
+    groups = {}
+    for i in range(plan0.n_ops):
+        op = plan0.op_array[i]
+        d = op.conv
+        one = C.cast(C.byref(plan0.op_array, i * C.sizeof(YoloOp)), C.POINTER(YoloOp))
+        ts = []
+        for _ in range(repeat):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            K.run_ops(one, 1)
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        ms = statistics.median(ts)
+        if op.kind == OP_STEM:
+            label, fl = "stem (conv 3x3 3->32 + 3x3/s2 32->64, one launch)", 2.0 * d.n * d.h * d.w * 32 * 27 + 2.0 * d.n * d.ho * d.wo * 64 * 288
+        elif op.kind == OP_RESUNIT:
+            label, fl = f"fused residual unit C={d.cout} @{d.h}x{d.w}", 2.0 * d.n * d.h * d.w * (d.cout * d.cin) * 10
+        elif op.kind in (OP_CONV, OP_CONV1_NCHW, OP_CONV1_POOL, OP_CONV_POOL, OP_HEAD_DECODE):
+            fl = 2.0 * d.n * d.ho * d.wo * d.cout * d.ksize * d.ksize * d.cin
+            label = (f"conv {d.ksize}x{d.ksize}/s{d.stride} @{d.ho}x{d.wo}" + (" head+decode" if op.kind == OP_HEAD_DECODE else ""))
+        else:
+            label, fl = f"op kind {op.kind}", 0.0
+        g = groups.setdefault(label, dict(label=label, launches=0, ms=0.0, flops=0.0))
+        g["launches"] += 1
+        g["ms"] += ms
+        g["flops"] += fl
+    return sorted(groups.values(), key=lambda g: -g["ms"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,29 +198,45 @@ def main():
     ap.add_argument("--bs", type=int, default=0, help="images per GPU (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=2, help="concurrent sub-batch streams per GPU (1 = off)")
+    ap.add_argument("--no-api", action="store_true", help="skip the API-level model.detect() timing")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: rehearse the N-rank launcher and the all-gather over gloo, print a line with value null")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    if "RANK" not in os.environ and (args.gpus > 1 or args.dry_run):
+        sys.exit(launch_ranks(args, sys.argv[1:]))               # BEFORE any GPU call in this process
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus {args.gpus}` or under "
+                         f"torch.distributed.run with --nproc-per-node {args.gpus}")
+    if args.dry_run:
+        sys.exit(dry_run(args, world, rank))
     # rehearsal on a one-GPU box only: YOLO_BENCH_REHEARSE=1 puts every rank on cuda:0 and uses gloo (RCCL refuses two
     # ranks on one device); the numbers of such a run mean nothing, it exercises the sharded control flow
     rehearse = os.environ.get("YOLO_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank} but only {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # under torch.distributed.run (RANK set) the sharded path runs even with one rank, so that it can be rehearsed
     # on a single GPU; the plain `python bench.py` of the N=1 contract stays collective-free
     sharded = world > 1 or ("RANK" in os.environ and os.environ.get("YOLO_BENCH_SHARDED_AT_1") == "1")
+    backend = None
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        backend = dist.get_backend()
+        assert dist.get_world_size() == args.gpus
 
     wl = WORKLOADS[args.workload]
     bs = args.bs or wl["bs"]
@@ -197,11 +303,32 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
 
-    traffic = None
-    try:        # HBM bytes of the conv launch list per step, from the committed rocprofv3 --pmc passes (cannot be read live)
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_conv_traffic.json")))
+    # API-level number beside the device-level one: model.detect() as a caller sees it (fresh output tensors every call, the
+    # count D2H copy and the list[Tensor | None] split inside the timed region, host-synchronous); sharded runs time
+    # detect_sharded (forward + NMS + all-gather + split on every rank)
+    api_ips = None
+    if not args.no_api:
+        from pytorch_yolo_amd.distributed import detect_sharded
+        k_api = max(3, min(args.steps, 20))
+        with torch.no_grad():
+            call = (lambda: detect_sharded(model, x, CONF_THRES, NMS_THRES)) if sharded else (lambda: model.detect(x, CONF_THRES, NMS_THRES))
+            call()
+            sync_all()
+            ta = time.perf_counter()
+            for _ in range(k_api):
+                res = call()
+            sync_all()
+            tb = torch.tensor([time.perf_counter() - ta], dtype=torch.float64, device=dev)
+        if sharded:
+            dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+        api_ips = round(bs * world * k_api / float(tb.item()), 2)
+        assert len(res) == bs * world
+
+    traffic, traffic_src = None, None
+    try:        # HBM bytes of the conv launch list per step: from committed rocprofv3 --pmc passes of this command, not live
+        tj = json.load(open(os.path.join(ROOT, "profiles", "conv_traffic.json")))
         if tj["workload"] == args.workload and tj["images_per_gpu"] == bs:
-            traffic = tj["hbm_bytes_per_step"]
+            traffic, traffic_src = tj["hbm_bytes_per_step"], tj.get("source", "profiles/conv_traffic.json") + " (rocprofv3 --pmc passes, NOT measured in this run)"
     except (OSError, KeyError, ValueError):
         pass
 
@@ -209,6 +336,19 @@ def main():
         total_imgs = bs * world * args.steps
         conv_ms_avg = sum(conv_ms) / len(conv_ms)
         achieved = flops_step / (conv_ms_avg * 1e-3) / 1e12
+        cfg = {"workload": wl["name"], "images_per_gpu": bs, "global_batch": bs * world,
+               "n_class": nc, "conf_thres": CONF_THRES, "nms_thres": NMS_THRES,
+               "sharding": f"batch x{world}" + (" + RCCL all-gather of detections (side stream)" if sharded else ""),
+               "mean_detections_per_image": round(sum(n_dets) / max(1, len(n_dets)), 1),
+               "streams_per_gpu": n_streams, "precision": model.precision}
+        if sharded:
+            cfg["rccl_ranks"], cfg["backend"] = dist.get_world_size(), backend
+            try:
+                cfg["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:                                    # noqa: BLE001 (version query only)
+                pass
+        if api_ips is not None:
+            cfg["detect_api_images_per_s"] = api_ips
         out = {
             "metric": "images/sec YOLOv3-SPP 640x640 bs=32 detect()" if args.workload == "spp" else f"images/sec {wl['name']}",
             "value": round(total_imgs / dt_max, 2),
@@ -222,16 +362,22 @@ def main():
             "vs_baseline": None,
             "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": wl["name"], "images_per_gpu": bs, "global_batch": bs * world,
-                       "n_class": nc, "conf_thres": CONF_THRES, "nms_thres": NMS_THRES,
-                       "sharding": f"batch x{world}" + (" + RCCL all-gather of detections (side stream)" if sharded else ""),
-                       "mean_detections_per_image": round(sum(n_dets) / max(1, len(n_dets)), 1),
-                       "streams_per_gpu": n_streams},
+            "config": cfg,
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "conv-family launch list of one forward (stem, resunit, conv_igemm_bf16 incl. head+decode, conv3x3_halo); per step the longest of the concurrent per-stream lists",
                          "flops_per_step": flops_step, "ms_per_step_conv": round(conv_ms_avg, 4)},
         }
+        if world == 1:
+            # the dominant kernel family by itself, live: every launch of one sub-batch list timed alone with HIP events
+            with torch.no_grad():
+                tab = solo_kernel_table(plan.subs[0] if hasattr(plan, "subs") else plan)
+            top = tab[0]
+            tf = top["flops"] / (top["ms"] * 1e-3) / 1e12
+            out["roofline"]["dominant_kernel"] = {
+                "label": top["label"], "launches_per_sub_batch": top["launches"], "avg_ms_solo": round(top["ms"] / top["launches"], 4),
+                "flops_per_launch": top["flops"] / top["launches"], "achieved": round(tf, 1), "frac": round(tf / PEAK_BF16_TFLOPS, 4),
+                "share_of_list_time": round(top["ms"] / sum(g["ms"] for g in tab), 3)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)

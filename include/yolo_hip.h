@@ -225,11 +225,31 @@ YOLO_API int yolo_letterbox_u8_fwd(const uint8_t* src, int h, int w, int c, int 
                                    int rw, int top, int left, int th, int tw, uint8_t* dst_u8, float* dst_f32,
                                    int dst_h, int dst_w, int off_y, int off_x, float fill, yolo_stream_t s);
 
+/* ---- fp32 "reference-precision" mode: the same operators with float32 NHWC activations and float32 weights, the
+ *  contraction on v_mfma_f32_32x32x2_f32 (exact f32 products, f32 accumulation) - the arithmetic of the reference's fp32
+ *  ATen ops up to summation order.  ~1/16 of the bf16 MFMA rate: a parity mode (model.precision = "fp32"), not the bench.
+ *  yolo_conv2d_f32_fwd: ConvBlock.forward / plain heads / Add / Upsample / Concat placement exactly as yolo_conv2d_fwd
+ *  (models/yolo_base.py:19-44, yolov3_tiny.py:38,42, yolov3_spp.py:12-14, yolo_layer.py:6-22); views are multiples of 4
+ *  channels, w_packed f32 [cout_pad][kpad] (yolo_pack_conv_weight_f32_f32; kpad multiple of 32, cout_pad of 128),
+ *  d->out_dtype is ignored (always f32), any odd ksize <= 7.
+ *  yolo_maxpool_f32_fwd: MaxPool (models/yolo_base.py:60-66); the SPP pyramid (yolov3_spp.py:75-77) is three calls
+ *  (5 / 9 / 13, stride 1) from slice [3c,4c) into slices [0,c) [c,2c) [2c,3c) of the concat buffer.
+ *  yolo_pack_input_nchw_f32_nhwc: the layout step in front of the first conv, channels zero-padded to c_pad. */
+YOLO_API int yolo_conv2d_f32_fwd(const float* x, const float* w_packed, const float* bias, const float* residual, float* y,
+                                 float* y_preadd, const YoloConvDesc* d, yolo_stream_t s);
+YOLO_API int yolo_maxpool_f32_fwd(const float* x, float* y, int n, int h, int w, int c, int in_c_total, int in_c_offset, int ho,
+                                  int wo, int out_c_total, int out_c_offset, int ksize, int stride, int pad, int dilation,
+                                  yolo_stream_t s);
+YOLO_API int yolo_pack_input_nchw_f32_nhwc(const float* x, float* y, int n, int c, int h, int w, int c_pad, yolo_stream_t s);
+YOLO_API int yolo_pack_conv_weight_f32_f32(const float* w_oihw, int cout, int cin_w, int ksize, int cin, int cout_pad, int kpad,
+                                           float* out);
+
 /* ---- batched launcher: run a recorded list of ops with one FFI crossing (host overhead only). */
 enum { YOLO_OP_CONV = 1, YOLO_OP_MAXPOOL = 2, YOLO_OP_SPP = 3, YOLO_OP_DWCONV = 4, YOLO_OP_CONV1_NCHW = 5,
        YOLO_OP_RESUNIT = 6, YOLO_OP_STEM = 7, YOLO_OP_HEAD_DECODE = 8, YOLO_OP_CONV1_POOL = 9, YOLO_OP_MBCONV = 10,
        YOLO_OP_CONV_POOL = 11 /* yolo_conv3x3_pool_fwd with pool = 1: x = bf16 NHWC, y = the pooled map */,
-       YOLO_OP_SHUFFLE = 12 /* yolo_channel_shuffle2_fwd: x = a, residual = b, conv.cin = c_slot, conv.cout = half, res_* = view of b */ };
+       YOLO_OP_SHUFFLE = 12 /* yolo_channel_shuffle2_fwd: x = a, residual = b, conv.cin = c_slot, conv.cout = half, res_* = view of b */,
+       YOLO_OP_CONV_F32 = 13 /* yolo_conv2d_f32_fwd */, YOLO_OP_MAXPOOL_F32 = 14 /* yolo_maxpool_f32_fwd, fields as MAXPOOL */ };
 typedef struct YoloOp {
   int32_t kind, _pad;
   const void* x; const void* w; const float* bias; const void* residual; void* y; void* y_aux;

@@ -14,6 +14,27 @@ import torch.nn.functional as F
 BN_EPS = 1e-5          # nn.BatchNorm2d default, /root/reference/pytorch_yolo/models/yolo_base.py:37
 LEAKY_SLOPE = 0.1      # yolo_base.py:38
 
+# Optional observer of intermediate tensors (tools/drift_trace.py, tests): called as tap(name, tensor) with the block's
+# state_dict prefix ("down3.seq2.1", ...; residual sums as "<stage>.add<i>").  None: no overhead, nothing changes.
+# An observer may return a tensor to take the place of the observed one (precision-policy emulation in
+# tools/drift_model.py: e.g. round the residual stream to bf16); returning None leaves the value alone.
+_TAP = None
+
+
+def set_tap(fn):
+    """Install (or with None remove) the observer; returns the previous one."""
+    global _TAP
+    prev, _TAP = _TAP, fn
+    return prev
+
+
+def tap(name, t):
+    if _TAP is not None:
+        r = _TAP(name, t)
+        if r is not None:
+            return r
+    return t
+
 
 def conv_bn_leaky(sd, prefix, x, stride=1, pad=True):
     """ConvBlock.forward — yolo_base.py:19-44.
@@ -27,19 +48,19 @@ def conv_bn_leaky(sd, prefix, x, stride=1, pad=True):
         k = fused_w.shape[-1]
         y = F.conv2d(x, fused_w, sd[prefix + ".sequence.0.bias"], stride=stride,
                      padding=(k - 1) // 2 if pad else 0)
-        return F.leaky_relu(y, LEAKY_SLOPE)
+        return tap(prefix, F.leaky_relu(y, LEAKY_SLOPE))
     w = sd[prefix + ".sequence.conv.weight"]
     k = w.shape[-1]
     y = F.conv2d(x, w, None, stride=stride, padding=(k - 1) // 2 if pad else 0)
     bn = prefix + ".sequence.batch_norm."
     y = F.batch_norm(y, sd[bn + "running_mean"], sd[bn + "running_var"],
                      sd[bn + "weight"], sd[bn + "bias"], training=False, eps=BN_EPS)
-    return F.leaky_relu(y, LEAKY_SLOPE)
+    return tap(prefix, F.leaky_relu(y, LEAKY_SLOPE))
 
 
 def plain_conv1x1(sd, prefix, x):
     """nn.Conv2d(C, 255, kernel_size=1) with bias — yolov3_tiny.py:38,42."""
-    return F.conv2d(x, sd[prefix + ".weight"], sd[prefix + ".bias"])
+    return tap(prefix, F.conv2d(x, sd[prefix + ".weight"], sd[prefix + ".bias"]))
 
 
 def fold_bn(conv_w, gamma, beta, mean, var, conv_b=None, eps=BN_EPS):

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import torch
 
-from .blocks import (conv_bn_leaky, max_pool, plain_conv1x1, upsample2,
+from .blocks import (conv_bn_leaky, max_pool, plain_conv1x1, tap, upsample2,
                      yolo_decode)
 
 SPP_STAGE_REPEATS = (1, 2, 8, 8, 4)   # DownSample(repeat=0,1,7,7,3)+1, yolov3_spp.py:63-67,22
@@ -32,7 +32,7 @@ def darknet_stage(sd, prefix, x, repeats):
     for i in range(repeats):
         sub = conv_bn_leaky(sd, f"{prefix}.seq{i}.0", x)            # 1x1 C -> C/2
         sub = conv_bn_leaky(sd, f"{prefix}.seq{i}.1", sub)          # 3x3 C/2 -> C
-        x = x + sub                                                 # Add, :12-14
+        x = tap(f"{prefix}.add{i}", x + sub)                        # Add, :12-14
     return x, sub
 
 

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("YOLO_HIP_LIB") or os.path.join(_HERE, "csrc", "libyol
 ACT_NONE, ACT_LEAKY01, ACT_RELU6, ACT_RELU = 0, 1, 2, 3
 DT_BF16, DT_F32 = 0, 1
 OP_CONV, OP_MAXPOOL, OP_SPP, OP_DWCONV, OP_CONV1_NCHW, OP_RESUNIT, OP_STEM, OP_HEAD_DECODE, OP_CONV1_POOL = 1, 2, 3, 4, 5, 6, 7, 8, 9
-OP_MBCONV, OP_CONV_POOL, OP_SHUFFLE = 10, 11, 12
+OP_MBCONV, OP_CONV_POOL, OP_SHUFFLE, OP_CONV_F32, OP_MAXPOOL_F32 = 10, 11, 12, 13, 14
 
 
 class YoloConvDesc(C.Structure):
@@ -85,6 +85,10 @@ SIGNATURES = {
     "yolo_scale_coords": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "yolo_letterbox_u8_fwd": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_double] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p] +
                               [C.c_int] * 4 + [C.c_float, C.c_void_p]),
+    "yolo_conv2d_f32_fwd": (C.c_int, [C.c_void_p] * 6 + [C.POINTER(YoloConvDesc), C.c_void_p]),
+    "yolo_maxpool_f32_fwd": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 14 + [C.c_void_p]),
+    "yolo_pack_input_nchw_f32_nhwc": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
+    "yolo_pack_conv_weight_f32_f32": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
     "yolo_run_ops": (C.c_int, [C.POINTER(YoloOp), C.c_int, C.c_void_p]),
 }
 

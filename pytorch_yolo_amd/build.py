@@ -23,6 +23,7 @@ SOURCES = {
     "conv_stem.hip": [],
     "conv_mbconv.hip": [],
     "conv_small.hip": [],
+    "conv_f32.hip": ["-ffp-contract=off"],
     "pointwise.hip": [],
     "preprocess.hip": ["-ffp-contract=off"],
     "nms.hip": ["-ffp-contract=off"],

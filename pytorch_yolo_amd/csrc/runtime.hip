@@ -59,6 +59,13 @@ extern "C" int yolo_run_ops(const YoloOp* ops, int n_ops, yolo_stream_t s) {
         rc = yolo_channel_shuffle2_fwd(o.x, o.residual, o.y, d.n, d.h, d.w, d.cout, d.cin, d.in_c_total, d.in_c_offset, d.res_c_total,
                                        d.res_c_offset, d.out_c_total, d.out_c_offset, s);
         break;
+      case YOLO_OP_CONV_F32:
+        rc = yolo_conv2d_f32_fwd((const float*)o.x, (const float*)o.w, o.bias, (const float*)o.residual, (float*)o.y, (float*)o.y_aux, &d, s);
+        break;
+      case YOLO_OP_MAXPOOL_F32:
+        rc = yolo_maxpool_f32_fwd((const float*)o.x, (float*)o.y, d.n, d.h, d.w, d.cin, d.in_c_total, d.in_c_offset, d.ho, d.wo,
+                                  d.out_c_total, d.out_c_offset, d.ksize, d.stride, d.pad, d.upsample2x /* dilation */, s);
+        break;
       case YOLO_OP_CONV_POOL:
         rc = yolo_conv3x3_pool_fwd(o.x, o.w, o.bias, o.y, &d, 1, s);
         break;

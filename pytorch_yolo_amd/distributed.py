@@ -22,20 +22,37 @@ def shard_bounds(total: int, world: int, rank: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_detections(dets: torch.Tensor, count: torch.Tensor, group=None, gather_cap: int = 1024):
+def gather_detections(dets: torch.Tensor, count: torch.Tensor, group=None, gather_cap: int = 1024, equal_shards: bool = False):
     """All-gather per-rank NMS outputs.
 
     dets [bs_local, cap, 7] float32, count [bs_local] int32 (device or CPU tensors, any backend).
-    Every rank must hold the same bs_local.  Returns (all_dets [world*bs_local, gather_cap, 7],
-    all_count [world*bs_local]) on every rank, images in global (rank-major) order."""
+    Ranks may hold different bs_local (``shard_bounds`` spreads a remainder over the first ranks): the shard sizes are
+    exchanged first and every shard is zero-padded to the largest one for the fixed-size all-gather; pass
+    ``equal_shards=True`` to skip that exchange when every rank is known to hold the same bs_local.
+    Returns (all_dets [sum bs_local, gather_cap, 7], all_count [sum bs_local]) on every rank, images in global
+    (rank-major) order."""
     world = dist.get_world_size(group)
     bs, cap, _ = dets.shape
     g = min(gather_cap, cap)
+    sizes = [bs] * world
+    if not equal_shards:
+        mine = torch.tensor([bs], dtype=torch.int64, device=count.device)
+        every = torch.empty((world,), dtype=torch.int64, device=count.device)
+        dist.all_gather_into_tensor(every, mine, group=group)
+        sizes = every.tolist()
+    top = max(sizes)
     send = dets[:, :g].contiguous()
-    all_dets = torch.empty((world * bs, g, 7), dtype=dets.dtype, device=dets.device)
-    all_count = torch.empty((world * bs,), dtype=count.dtype, device=count.device)
-    dist.all_gather_into_tensor(all_count, count.contiguous(), group=group)
+    send_count = count.contiguous()
+    if bs < top:                                   # pad this shard: fixed-size buffers on the wire
+        send = torch.cat([send, send.new_zeros((top - bs, g, 7))], 0)
+        send_count = torch.cat([send_count, send_count.new_zeros((top - bs,))], 0)
+    all_dets = torch.empty((world * top, g, 7), dtype=dets.dtype, device=dets.device)
+    all_count = torch.empty((world * top,), dtype=count.dtype, device=count.device)
+    dist.all_gather_into_tensor(all_count, send_count, group=group)
     dist.all_gather_into_tensor(all_dets, send, group=group)
+    if any(sz != top for sz in sizes):             # drop the pad rows, keep rank-major image order
+        keep = torch.cat([torch.arange(r * top, r * top + sz) for r, sz in enumerate(sizes)]).to(all_count.device)
+        all_dets, all_count = all_dets.index_select(0, keep.to(all_dets.device)), all_count.index_select(0, keep)
     return all_dets, all_count
 
 

@@ -27,8 +27,9 @@ from typing import List, Optional
 import torch
 
 from . import kernels as K
-from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU, ACT_RELU6, DT_BF16, DT_F32, OP_CONV, OP_CONV1_NCHW, OP_DWCONV,
-                   OP_CONV1_POOL, OP_CONV_POOL, OP_MBCONV, OP_SHUFFLE, OP_HEAD_DECODE, OP_MAXPOOL, OP_RESUNIT, OP_SPP, OP_STEM, YoloOp)
+from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU, ACT_RELU6, DT_BF16, DT_F32, OP_CONV, OP_CONV1_NCHW, OP_CONV_F32, OP_DWCONV,
+                   OP_CONV1_POOL, OP_CONV_POOL, OP_MAXPOOL_F32, OP_MBCONV, OP_SHUFFLE, OP_HEAD_DECODE, OP_MAXPOOL, OP_RESUNIT, OP_SPP,
+                   OP_STEM, YoloOp)
 
 # which residual-unit widths run as ONE launch (bit mask of C: 64 | 128 | 256); see DESIGN.md §3.1d for the
 # measurements behind the default.  YOLO_FUSE_RESUNIT overrides it (tuning only).
@@ -90,7 +91,8 @@ class Recorder:
         return node
 
     # weight = (w_oihw f32, bias f32) already BN-folded; act in {'leaky','relu6','none'}
-    def conv(self, x: Sym, weight, stride=1, act="leaky", residual: Sym = None, want_preadd=False, f32_out=False, pad=None):
+    def conv(self, x: Sym, weight, stride=1, act="leaky", residual: Sym = None, want_preadd=False, f32_out=False, pad=None,
+             name=None):
         w, _ = weight
         cout, cin_w, k, _ = w.shape
         if cin_w > x.c:
@@ -105,7 +107,7 @@ class Recorder:
         if want_preadd:
             outs.append(Sym(x.n, ho, wo, cout, slot=1))
         srcs = [x] + ([residual] if residual is not None else [])
-        self._add("conv", srcs, outs, weight=weight, stride=stride, act=act, has_res=residual is not None)
+        self._add("conv", srcs, outs, weight=weight, stride=stride, act=act, has_res=residual is not None, name=name)
         if pad != same:
             self.nodes[-1].attrs["pad"] = pad            # (SqueezeNet's unpadded first conv; no fused form takes it)
         return (y, outs[1]) if want_preadd else y
@@ -177,9 +179,17 @@ _ACT = {"leaky": ACT_LEAKY01, "relu6": ACT_RELU6, "relu": ACT_RELU, "none": ACT_
 
 # ------------------------------------------------------------------------------------------------
 class Plan:
-    """Buffers + packed weights + launch list for one (batch, H, W) on one device."""
+    """Buffers + packed weights + launch list for one (batch, H, W) on one device.
 
-    def __init__(self, rec: Recorder, device, n_class: int, img_size: int):
+    ``precision``: "bf16" (default: bf16 activations / weights, fp32 accumulate, every fusion) or "fp32" (the
+    reference-precision parity mode: float32 activations and weights on the f32 MFMA, one plain launch per layer,
+    csrc/conv_f32.hip)."""
+
+    def __init__(self, rec: Recorder, device, n_class: int, img_size: int, precision: str = "bf16"):
+        if precision not in ("bf16", "fp32"):
+            raise ValueError(f"precision must be 'bf16' or 'fp32', got {precision!r}")
+        self.f32 = precision == "fp32"
+        self.precision = precision
         self.device = device
         self.rec = rec
         self.n_class = n_class
@@ -234,7 +244,7 @@ class Plan:
                 x.producer.attrs["up_into"] = y
         # 2b. Darknet residual units (1x1 C->C/2, 3x3 C/2->C, add) on the large maps: one launch (yolo_resunit_fwd);
         #     the intermediate never leaves the chip and the output gets its own buffer (no in-place add there)
-        fuse_mask = int(os.environ.get("YOLO_FUSE_RESUNIT", str(FUSE_RESUNIT_DEFAULT)))
+        fuse_mask = 0 if self.f32 else int(os.environ.get("YOLO_FUSE_RESUNIT", str(FUSE_RESUNIT_DEFAULT)))
         for nd in nodes:
             if nd.kind != "conv" or not nd.attrs["has_res"] or "up_into" in nd.attrs:
                 continue
@@ -255,7 +265,7 @@ class Plan:
         # 2c. MobileNetV2 inverted-residual blocks (1x1 expand + ReLU6, depthwise 3x3 + ReLU6, linear 1x1 [+ x]) with
         #     few channels, i.e. the large maps: one launch (yolo_mbconv_fwd), the 6x-expanded tensor and the
         #     depthwise output never exist in HBM; the output gets its own buffer (neighbouring tiles read x)
-        if os.environ.get("YOLO_FUSE_MBCONV", "1") == "1":
+        if os.environ.get("YOLO_FUSE_MBCONV", "1") == "1" and not self.f32:
             for nd in nodes:
                 if (nd.kind != "conv" or "up_into" in nd.attrs or len(nd.outs) != 1 or nd.outs[0].f32
                         or nd.attrs["act"] != "none" or nd.attrs["stride"] != 1 or nd.attrs["weight"][0].shape[2] != 1):
@@ -279,7 +289,7 @@ class Plan:
                         ex.attrs["fused_away"] = True
         # 2d. ConvPoolBlocks with few input channels (YOLOv3-tiny's second and third: 16 -> 32, 32 -> 64): conv + MaxPool2d(2, 2)
         #     in one launch (yolo_conv3x3_pool_fwd), the full-resolution conv output is never written
-        if os.environ.get("YOLO_FUSE_POOL", "1") == "1":
+        if os.environ.get("YOLO_FUSE_POOL", "1") == "1" and not self.f32:
             for nd in nodes:
                 if (nd.kind != "conv" or nd.attrs["has_res"] or len(nd.outs) != 1 or "up_into" in nd.attrs or nd.attrs["stride"] != 1
                         or nd.attrs.get("fused_away") or nd.srcs[0] is self.rec.input):
@@ -305,7 +315,7 @@ class Plan:
                 elif dead and y.buf is None and res.buf is None:
                     nd.attrs["alias_res"] = True
         # 3b. detection heads: the head conv decodes in its epilogue (yolo_head_decode_fwd); no head tensor
-        if os.environ.get("YOLO_FUSE_HEAD", "1") == "1":
+        if os.environ.get("YOLO_FUSE_HEAD", "1") == "1" and not self.f32:
             for nd in nodes:
                 layer = self._head_layer(nd)
                 if layer is None or nd.attrs["has_res"] or len(nd.outs) != 1 or "up_into" in nd.attrs or nd.attrs["stride"] != 1:
@@ -354,7 +364,7 @@ class Plan:
         """The first layer can read the caller's float32 NCHW batch itself (yolo_conv1_nchw_f32_fwd): then the
         NHWC bf16 copy of the input is never materialised."""
         x = self.rec.input
-        if len(x.consumers) != 1 or x.consumers[0].kind != "conv" or self.rec.c_in > 8:
+        if self.f32 or len(x.consumers) != 1 or x.consumers[0].kind != "conv" or self.rec.c_in > 8:
             return False
         nd = x.consumers[0]
         w, _ = nd.attrs["weight"]
@@ -410,7 +420,7 @@ class Plan:
 
     def _alloc(self):
         for b in self._bufs:
-            dt = torch.float32 if b.f32 else torch.bfloat16
+            dt = torch.float32 if (b.f32 or self.f32) else torch.bfloat16
             ct = K.roundup(b.c_total, 8)
             b.c_total = ct
             # zero-filled once: padded channels (e.g. 255 -> 256 head rows) are never written
@@ -432,7 +442,10 @@ class Plan:
             self.heads.append(dict(sym=x, anchors=layer.anchors_px, stride=stride, row=row, na=na, layer=layer, op=None))
             row += na * x.h * x.w
         self.rows_total = row
+        if self.f32:
+            return self._build_ops_f32()
         ops = []
+        op_nodes = []                                      # the graph node each launch comes from (tools/drift_trace.py)
         splitk_ops = []                                    # (op index, workspace bytes, counters) of the split-K launches
         for nd in self.rec.nodes:
             if nd.attrs.get("fused_away"):
@@ -452,7 +465,7 @@ class Plan:
                                       out_c_total=y.buf.c_total, out_c_offset=y.c_offset, ksize=3, stride=2,
                                       act=_ACT[nd.attrs["act"]], kpad=kpad2, cout_pad=cout_pad2)
                 op.conv.res_c_total = self.rec.c_in            # real input channels
-                ops.append(op)
+                ops.append(op); op_nodes.append(nd)
             elif nd.kind == "conv" and nd.attrs.get("head_fused"):
                 x, y = nd.srcs[0], nd.outs[0]
                 hd = next(h for h in self.heads if h["sym"] is y)
@@ -472,7 +485,7 @@ class Plan:
                 op.head_stride_px, op.head_na, op.head_nc = float(hd["stride"]), hd["na"], self.n_class
                 op.io_rows_total, op.io_row_offset = self.rows_total, hd["row"]
                 hd["op"] = len(ops)
-                ops.append(op)
+                ops.append(op); op_nodes.append(nd)
             elif nd.kind == "conv" and "mb_pre" in nd.attrs:
                 ex, dwn, x = nd.attrs["mb_pre"]
                 y = nd.outs[0]
@@ -490,7 +503,7 @@ class Plan:
                 d.n, d.h, d.w, d.cin, d.in_c_total, d.in_c_offset = x.n, x.h, x.w, x.c, x.buf.c_total, x.c_offset
                 d.ho, d.wo, d.cout, d.out_c_total, d.out_c_offset = y.h, y.w, y.c, y.buf.c_total, y.c_offset
                 d.ksize, d.stride, d.res_c_total = 3, dwn.attrs["stride"], 1 if nd.attrs["has_res"] else 0
-                ops.append(op)
+                ops.append(op); op_nodes.append(nd)
             elif nd.kind == "conv" and "fuse_pre" in nd.attrs:
                 pa = nd.attrs["fuse_pre"]
                 x, y, mid = nd.srcs[1], nd.outs[0], nd.srcs[0]
@@ -508,7 +521,7 @@ class Plan:
                                       cout=x.c, out_c_total=y.buf.c_total, out_c_offset=y.c_offset, ksize=3, stride=1,
                                       act=_ACT[nd.attrs["act"]], kpad=kpad2, cout_pad=cout_pad2,
                                       aux=(aux.buf.c_total, aux.c_offset) if aux is not None else (0, 0))
-                ops.append(op)
+                ops.append(op); op_nodes.append(nd)
             elif nd.kind == "conv":
                 x = nd.srcs[0]
                 y = nd.outs[0]
@@ -550,7 +563,7 @@ class Plan:
                 op.y = dst.buf.tensor.data_ptr()
                 op.y_aux = aux.buf.tensor.data_ptr() if aux is not None else None
                 op.conv = d
-                ops.append(op)
+                ops.append(op); op_nodes.append(nd)
             elif nd.kind == "dwconv":
                 x, y = nd.srcs[0], nd.outs[0]
                 w, b = nd.attrs["weight"]
@@ -563,7 +576,7 @@ class Plan:
                 d.n, d.h, d.w, d.cin = x.n, x.h, x.w, x.c
                 d.in_c_total, d.in_c_offset, d.ho, d.wo = x.buf.c_total, x.c_offset, y.h, y.w
                 d.out_c_total, d.out_c_offset, d.stride, d.act = y.buf.c_total, y.c_offset, nd.attrs["stride"], _ACT[nd.attrs["act"]]
-                ops.append(op)
+                ops.append(op); op_nodes.append(nd)
             elif nd.kind == "shuffle":
                 a_, b_, y = nd.srcs[0], nd.srcs[1], nd.outs[0]
                 op = YoloOp()
@@ -574,7 +587,7 @@ class Plan:
                 d.in_c_total, d.in_c_offset = a_.buf.c_total, a_.c_offset
                 d.res_c_total, d.res_c_offset = b_.buf.c_total, b_.c_offset
                 d.out_c_total, d.out_c_offset, d.cout = y.buf.c_total, y.c_offset, nd.attrs["half"]   # cout = logical half
-                ops.append(op)
+                ops.append(op); op_nodes.append(nd)
             elif nd.kind == "pool":
                 x, y = nd.srcs[0], nd.outs[0]
                 op = YoloOp()
@@ -585,7 +598,7 @@ class Plan:
                 d.in_c_total, d.in_c_offset, d.ho, d.wo = x.buf.c_total, x.c_offset, y.h, y.w
                 d.out_c_total, d.out_c_offset = y.buf.c_total, y.c_offset
                 d.ksize, d.stride, d.pad, d.upsample2x = nd.attrs["size"], nd.attrs["stride"], nd.attrs["pad"], nd.attrs["dil"]
-                ops.append(op)
+                ops.append(op); op_nodes.append(nd)
             elif nd.kind == "spp":
                 x, y = nd.srcs[0], nd.outs[0]
                 op = YoloOp()
@@ -593,14 +606,66 @@ class Plan:
                 op.y = y.buf.tensor.data_ptr()
                 d = op.conv
                 d.n, d.h, d.w, d.cin = x.n, x.h, x.w, x.c
-                ops.append(op)
+                ops.append(op); op_nodes.append(nd)
         if splitk_ops:      # one fp32 workspace and one zeroed counter array per plan: the launches run in stream order
             self._splitk_ws = torch.empty((max(w for _, w, _ in splitk_ops) + 3) // 4, dtype=torch.float32, device=self.device)
             self._splitk_cnt = torch.zeros(max(c for _, _, c in splitk_ops), dtype=torch.int32, device=self.device)
             for i, _, _ in splitk_ops:
                 ops[i].workspace, ops[i].counters = self._splitk_ws.data_ptr(), self._splitk_cnt.data_ptr()
         self.n_ops = len(ops)
+        self.op_nodes = op_nodes
         self.op_array = (YoloOp * len(ops))(*ops)
+    def _build_ops_f32(self):
+        """fp32 mode: one plain launch per recorded layer (yolo_conv2d_f32_fwd / yolo_maxpool_f32_fwd); concat, upsample and
+        residual placement are the same epilogue options as in the bf16 list, nothing else is fused."""
+        ops, op_nodes = [], []
+        for nd in self.rec.nodes:
+            if nd.kind == "conv":
+                x, y = nd.srcs[0], nd.outs[0]
+                w, b = nd.attrs["weight"]
+                wp, bp, kpad, cout_pad = K.pack_conv_weight_f32(w, b, x.c)
+                wp, bp = self._dev(wp), self._dev(bp)
+                up = nd.attrs.get("up_into")
+                dst = up if up is not None else y
+                res = nd.srcs[1] if nd.attrs["has_res"] else None
+                aux = nd.outs[1] if len(nd.outs) > 1 else None
+                op = YoloOp()
+                op.kind = OP_CONV_F32
+                op.conv = K.conv_desc(n=x.n, h=x.h, w=x.w, cin=x.c, in_c_total=x.buf.c_total, in_c_offset=x.c_offset,
+                                      cout=w.shape[0], out_c_total=dst.buf.c_total, out_c_offset=dst.c_offset,
+                                      ksize=w.shape[2], stride=nd.attrs["stride"], act=_ACT[nd.attrs["act"]], kpad=kpad,
+                                      cout_pad=cout_pad, upsample2x=1 if up is not None else 0, out_dtype=DT_F32,
+                                      pad=nd.attrs.get("pad"),
+                                      res=(res.buf.c_total, res.c_offset) if res is not None else (0, 0),
+                                      aux=(aux.buf.c_total, aux.c_offset) if aux is not None else (0, 0))
+                op.x, op.w, op.bias = x.buf.tensor.data_ptr(), wp.data_ptr(), bp.data_ptr()
+                op.residual = res.buf.tensor.data_ptr() if res is not None else None
+                op.y = dst.buf.tensor.data_ptr()
+                op.y_aux = aux.buf.tensor.data_ptr() if aux is not None else None
+                ops.append(op); op_nodes.append(nd)
+            elif nd.kind in ("pool", "spp"):
+                x, y = nd.srcs[0], nd.outs[0]
+                if nd.kind == "pool":
+                    jobs = [(nd.attrs["size"], nd.attrs["stride"], nd.attrs["pad"], nd.attrs["dil"], y.c_offset)]
+                else:            # cat([p5, p9, p13, x]) (yolov3_spp.py:129): x already sits in slice [3c, 4c)
+                    jobs = [(k, 1, k // 2, 1, y.c_offset + lvl * x.c) for lvl, k in enumerate((5, 9, 13))]
+                for k, st, pad, dil, out_off in jobs:
+                    op = YoloOp()
+                    op.kind = OP_MAXPOOL_F32
+                    op.x, op.y = x.buf.tensor.data_ptr(), y.buf.tensor.data_ptr()
+                    d = op.conv
+                    d.n, d.h, d.w, d.cin = x.n, x.h, x.w, x.c
+                    d.in_c_total, d.in_c_offset, d.ho, d.wo = x.buf.c_total, x.c_offset, y.h, y.w
+                    d.out_c_total, d.out_c_offset = y.buf.c_total, out_off
+                    d.ksize, d.stride, d.pad, d.upsample2x = k, st, pad, dil
+                    ops.append(op); op_nodes.append(nd)
+            elif nd.kind in ("dwconv", "shuffle"):
+                raise NotImplementedError("precision='fp32' covers the Darknet families (YOLOv3-SPP / -tiny / YOLOv3 / Lite); "
+                                          f"no fp32 kernel for '{nd.kind}' layers")
+        self.n_ops = len(ops)
+        self.op_nodes = op_nodes
+        self.op_array = (YoloOp * len(ops))(*ops)
+
     # -- execution -----------------------------------------------------------------------------------
     @property
     def input_buffer(self) -> torch.Tensor:
@@ -613,6 +678,8 @@ class Plan:
             if x.dtype != torch.float32 or not x.is_contiguous() or tuple(x.shape[1:]) != (self.rec.c_in, self.rec.input.h, self.rec.input.w):
                 raise RuntimeError("input must be contiguous float32 NCHW of the planned shape")
             self.op_array[0].x = x.data_ptr()
+        elif self.f32:
+            K.pack_input_f32(x, self.input_buffer)
         else:
             K.pack_input(x, self.input_buffer)
 
@@ -662,7 +729,7 @@ class Plan:
         for i in range(self.n_ops):
             op = self.op_array[i]
             d = op.conv
-            if op.kind in (OP_CONV, OP_CONV1_NCHW, OP_CONV1_POOL, OP_CONV_POOL, OP_HEAD_DECODE):
+            if op.kind in (OP_CONV, OP_CONV1_NCHW, OP_CONV1_POOL, OP_CONV_POOL, OP_HEAD_DECODE, OP_CONV_F32):
                 cin = self.rec.c_in if first else d.cin      # the first layer's 3 -> 8 channel pad is not work
                 first = False
                 total += 2.0 * d.n * d.ho * d.wo * d.cout * d.ksize * d.ksize * cin
@@ -820,9 +887,10 @@ def run_standalone(trace_fn, x: torch.Tensor):
     bs, c, h, w = x.shape
     rec = Recorder(bs, c, h, w)
     out = trace_fn(rec, rec.input)
-    plan = Plan(rec, x.device, n_class=0, img_size=max(h, w))
-    plan.feed(x)
-    K.run_ops(plan.op_array, plan.n_ops)
-    if isinstance(out, (tuple, list)):
-        return tuple(_sym_to_nchw(s) for s in out)
-    return _sym_to_nchw(out)
+    with torch.cuda.device(x.device):               # the library launches on the current device's stream: make it x's
+        plan = Plan(rec, x.device, n_class=0, img_size=max(h, w))
+        plan.feed(x)
+        K.run_ops(plan.op_array, plan.n_ops)
+        if isinstance(out, (tuple, list)):
+            return tuple(_sym_to_nchw(s) for s in out)
+        return _sym_to_nchw(out)

@@ -50,6 +50,53 @@ def pack_conv_weight(w_oihw: torch.Tensor, bias: torch.Tensor | None, cin: int):
     return packed.to(torch.bfloat16).contiguous(), b, kpad, cout_pad
 
 
+def pack_conv_weight_f32(w_oihw: torch.Tensor, bias: torch.Tensor | None, cin: int):
+    """fp32 mode: OIHW f32 weights (+bias) -> (f32 [cout_pad, kpad], f32 [cout_pad]) on the host, same k order as the bf16 form
+    (kpad = roundup(k*k*cin, 32), cout_pad = roundup(cout, 128))."""
+    w = w_oihw.detach().float().cpu()
+    cout, cin_w, k, _ = w.shape
+    kpad, cout_pad = roundup(k * k * cin, 32), roundup(cout, 128)
+    packed = torch.zeros((cout_pad, k * k, cin), dtype=torch.float32)
+    packed[:cout, :, :cin_w] = w.permute(0, 2, 3, 1).reshape(cout, k * k, cin_w)
+    packed = torch.nn.functional.pad(packed.reshape(cout_pad, k * k * cin), (0, kpad - k * k * cin))
+    b = torch.zeros(cout_pad, dtype=torch.float32)
+    if bias is not None:
+        b[:cout] = bias.detach().float().cpu()
+    return packed.contiguous(), b, kpad, cout_pad
+
+
+def pack_input_f32(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """fp32 mode: f32 NCHW -> f32 NHWC (channels zero-padded to out.shape[-1])."""
+    _need_cuda(x, out)
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise RuntimeError("pack_input_f32: x must be contiguous float32 NCHW")
+    n, c, h, w = x.shape
+    if out.dtype != torch.float32 or tuple(out.shape[:3]) != (n, h, w) or not out.is_contiguous():
+        raise RuntimeError("pack_input_f32: out must be contiguous f32 [n,h,w,c_pad]")
+    check(load().yolo_pack_input_nchw_f32_nhwc(_ptr(x), _ptr(out), n, c, h, w, out.shape[3], stream_ptr()), "pack_input_f32")
+    return out
+
+
+def conv2d_f32(x, w_packed, bias, y, desc: YoloConvDesc, residual=None, y_preadd=None):
+    """fp32 mode conv (yolo_conv2d_f32_fwd): all tensors float32, ``desc`` as for conv2d with the fp32 packing sizes."""
+    _need_cuda(x, w_packed, bias, y, residual, y_preadd)
+    for t in (x, w_packed, bias, y, residual, y_preadd):
+        if t is not None and t.dtype != torch.float32:
+            raise RuntimeError("conv2d_f32: every tensor must be float32")
+    check(load().yolo_conv2d_f32_fwd(_ptr(x), _ptr(w_packed), _ptr(bias), _ptr(residual), _ptr(y), _ptr(y_preadd),
+                                     C.byref(desc), stream_ptr()), "conv2d_f32")
+    return y
+
+
+def maxpool_f32(x, y, *, n, h, w, c, in_view, out_view, ksize, stride, pad, dilation=1):
+    _need_cuda(x, y)
+    ho = (h + 2 * pad - dilation * (ksize - 1) - 1) // stride + 1
+    wo = (w + 2 * pad - dilation * (ksize - 1) - 1) // stride + 1
+    check(load().yolo_maxpool_f32_fwd(_ptr(x), _ptr(y), n, h, w, c, in_view[0], in_view[1], ho, wo, out_view[0],
+                                      out_view[1], ksize, stride, pad, dilation, stream_ptr()), "maxpool_f32")
+    return y
+
+
 def pack_input(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     """f32 NCHW -> bf16 NHWC (channels zero-padded to out.shape[-1])."""
     _need_cuda(x, out)

@@ -9,6 +9,7 @@ in libyolo_hip.so.  There is no eager / CPU path.
 """
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -21,6 +22,11 @@ from .yolo_layer import YOLOLayer
 
 DEFAULT_ANCHORS = (((10.0, 14.0), (23.0, 27.0), (37.0, 58.0)),
                    ((81.0, 82.0), (135.0, 169.0), (344.0, 319.0)))   # reference yolo_base.py:88-89
+
+# bumped whenever a block changes its module structure (ConvBlock.fuse on ANY block, also a sub-module's): cached plans
+# hold packed copies of the weights and are rebuilt when this moves (YOLOBase._fingerprint)
+_STRUCT_EPOCH = [0]
+MAX_CACHED_PLANS = 8          # per model: (shape, device, streams, precision) combinations kept (least recently used out)
 
 
 class ConvBlock(nn.Module):
@@ -58,9 +64,10 @@ class ConvBlock(nn.Module):
             return
         rest = [m for name, m in self.sequence.named_children() if name not in ("conv", "batch_norm")]
         self.sequence = nn.Sequential(fuse_conv_and_bn(self.sequence.conv, self.sequence.batch_norm), *rest)
+        _STRUCT_EPOCH[0] += 1
 
     def _trace(self, g: engine.Recorder, x, **kw):
-        return g.conv(x, self.folded(), stride=self.stride, act="leaky", **kw)
+        return g.conv(x, self.folded(), stride=self.stride, act="leaky", name=getattr(self, "_trace_name", None), **kw)
 
     def forward(self, x):
         return engine.run_standalone(lambda g, s: self._trace(g, s), x)
@@ -116,8 +123,12 @@ class YOLOBase(nn.Module):
         self.yolo_layer_input_size = 15 + 3 * n_class           # yolo_base.py:105
         self.encoder = None
         self._plans = {}
+        self._tensors = None
         self.use_hip_graph = False
         self.n_streams = 2          # sub-batches run concurrently on this many HIP streams (engine.StreamedPlan)
+        # "bf16": bf16 activations / weights with fp32 accumulation (the fast path); "fp32": float32 end to end on the f32
+        # MFMA — the reference's arithmetic up to summation order, ~20x slower, for parity checks (csrc/conv_f32.hip)
+        self.precision = os.environ.get("YOLO_PRECISION", "bf16")
 
     def _create_yolo_layers(self, device="cpu"):
         """One YOLOLayer per anchor group, in order (yolo_base.py:117-136)."""
@@ -126,6 +137,20 @@ class YOLOBase(nn.Module):
     # ---- cache control: any change of parameters invalidates the packed weights -------------------
     def invalidate(self):
         self._plans = {}
+        self._tensors = None
+
+    def _fingerprint(self):
+        """Cheap identity of the weights a cached plan was packed from: (structure epoch, storage address and in-place
+        version counter of every parameter / buffer).  It moves on sub-module load_state_dict / fuse, p.data.copy_,
+        nn.init.*, optimizer steps, .to() — everything that would otherwise leave a plan with stale packed weights."""
+        if self.__dict__.get("_tensors") is None or self.__dict__.get("_epoch_seen") != _STRUCT_EPOCH[0]:
+            self._epoch_seen = _STRUCT_EPOCH[0]
+            for m in self.modules():                  # assign=True loads replace Parameter objects: drop the tensor list then
+                if not m.__dict__.get("_yolo_hooked"):
+                    m.register_load_state_dict_post_hook(lambda _mod, _keys, _self=self: _self.invalidate())
+                    m.__dict__["_yolo_hooked"] = True
+            self._tensors = list(self.parameters()) + list(self.buffers())
+        return hash((self._epoch_seen, tuple((t.data_ptr(), t._version) for t in self._tensors)))
 
     def _apply(self, fn, *a, **kw):
         self.invalidate()
@@ -163,15 +188,27 @@ class YOLOBase(nn.Module):
                                "(there is no CPU fallback)")
         bs, c, h, w = x.shape
         n_streams = self.n_streams if (self.n_streams > 1 and bs % self.n_streams == 0 and bs // self.n_streams >= 4) else 1
-        key = (tuple(x.shape), x.device, n_streams)
-        plan = self._plans.get(key)
+        key = (tuple(x.shape), x.device, n_streams, self.precision)
+        fp = self._fingerprint()
+        if self.__dict__.get("_plans_fp") != fp:           # the weights changed since the plans were packed
+            self._plans = {}
+            self._plans_fp = fp
+        plan = self._plans.pop(key, None)
+        if plan is not None:
+            self._plans[key] = plan                          # most recently used last
         if plan is None:
+            for name, m in self.named_modules():          # reference key prefix of every block (drift traces, diagnostics)
+                m._trace_name = name
+
             def make(sub_bs):
                 rec = engine.Recorder(sub_bs, c, h, w)
                 self._trace(rec, rec.input)
-                return engine.Plan(rec, x.device, self.n_class, max(h, w))    # img_size, yolov3_spp.py:142
-            plan = make(bs) if n_streams == 1 else engine.StreamedPlan(make, bs, n_streams, x.device)
+                return engine.Plan(rec, x.device, self.n_class, max(h, w), self.precision)    # img_size, yolov3_spp.py:142
+            with torch.cuda.device(x.device):
+                plan = make(bs) if n_streams == 1 else engine.StreamedPlan(make, bs, n_streams, x.device)
             self._plans[key] = plan
+            while len(self._plans) > MAX_CACHED_PLANS:
+                self._plans.pop(next(iter(self._plans)))
         return plan
 
     def forward(self, x):
@@ -187,9 +224,10 @@ class YOLOBase(nn.Module):
         plan = self.plan_for(x)
         for hd in plan.heads:
             hd["layer"]._sync_grid_attrs(hd["sym"].h, hd["sym"].w, plan.img_size, x.device)
-        if self.use_hip_graph:
-            return plan.run_graph(x)
-        return plan.run(x)
+        with torch.cuda.device(x.device):           # the library launches on the CURRENT device's stream: make it x's
+            if self.use_hip_graph:
+                return plan.run_graph(x)
+            return plan.run(x)
 
     def detect(self, x, conf_thres=0.5, nms_thres=0.5):
         """The composition inside reference test_model (utils/utils.py:374-378):
@@ -199,10 +237,11 @@ class YOLOBase(nn.Module):
             raise NotImplementedError("detect() is an inference call: .eval() first")
         x = x.float().contiguous()
         plan = self.plan_for(x)
-        io, ps = plan.new_outputs()
-        bs, cap = x.shape[0], nms_capacity(plan.rows_total, self.n_class)
-        out = (torch.empty((bs, cap, 7), dtype=torch.float32, device=x.device),
-               torch.empty((bs, cap), dtype=torch.int32, device=x.device),
-               torch.empty((bs,), dtype=torch.int32, device=x.device))
-        plan.launch_detect(x, io, ps, out, conf_thres, nms_thres)
-        return split_detections(*out)
+        with torch.cuda.device(x.device):
+            io, ps = plan.new_outputs()
+            bs, cap = x.shape[0], nms_capacity(plan.rows_total, self.n_class)
+            out = (torch.empty((bs, cap, 7), dtype=torch.float32, device=x.device),
+                   torch.empty((bs, cap), dtype=torch.int32, device=x.device),
+                   torch.empty((bs,), dtype=torch.int32, device=x.device))
+            plan.launch_detect(x, io, ps, out, conf_thres, nms_thres)
+            return split_detections(*out)

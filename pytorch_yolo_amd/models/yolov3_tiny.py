@@ -19,7 +19,7 @@ class _Pool22(nn.MaxPool2d):
 def plain_head(g: engine.Recorder, x, conv: nn.Conv2d):
     """nn.Conv2d(C, 3*(5+nc), kernel_size=1) with bias, no BN / activation (yolov3_tiny.py:38,42)."""
     return g.conv(x, (conv.weight.detach().float().cpu(), conv.bias.detach().float().cpu()), stride=1,
-                  act="none", f32_out=True)
+                  act="none", f32_out=True, name=getattr(conv, "_trace_name", None))
 
 
 class YOLOv3Tiny(YOLOBase):

@@ -13,14 +13,21 @@ MIN_WH = 2.0               # reference utils.py:207
 MAX_PER_CLASS = 100        # reference utils.py:247-250
 
 _ws_cache = {}
+MAX_CACHED_WORKSPACES = 16
 
 
-def _workspace(device, bs, rows, nc, slot=0):
-    key = (device, bs, rows, nc, slot)
-    ws = _ws_cache.get(key)
+def _workspace(device, bs, rows, nc, slot=None):
+    """NMS scratch (keys / counters / staging), cached per (device, shape, STREAM): launches on one stream are ordered, so
+    they can share it; two same-shape calls on different streams get different buffers and cannot race.  Bounded: the
+    least recently used entry is dropped (its memory returns to torch's allocator once queued work has finished)."""
+    key = (device, bs, rows, nc, torch.cuda.current_stream(device).cuda_stream)
+    ws = _ws_cache.pop(key, None)
     if ws is None:
         ws = torch.empty(K.nms_workspace_bytes(bs, rows, nc), dtype=torch.uint8, device=device)
-        _ws_cache[key] = ws
+    _ws_cache[key] = ws                                  # most recently used last
+    while len(_ws_cache) > MAX_CACHED_WORKSPACES:
+        old = _ws_cache.pop(next(iter(_ws_cache)))
+        old.record_stream(torch.cuda.current_stream(device))
     return ws
 
 
@@ -49,18 +56,20 @@ def nms_raw(prediction: torch.Tensor, conf_thres: float, nms_thres: float, inpla
         out = (torch.empty((bs, cap, 7), dtype=torch.float32, device=dev),
                torch.empty((bs, cap), dtype=torch.int32, device=dev),
                torch.empty((bs,), dtype=torch.int32, device=dev))
-    K.nms_merge(prediction, conf_thres, nms_thres, out[0], out[1], out[2], _workspace(prediction.device, bs, rows, nc),
-                min_wh=MIN_WH, max_per_class=MAX_PER_CLASS, mutate_conf=inplace_conf)
+    with torch.cuda.device(prediction.device):          # the library launches on the current device's stream
+        K.nms_merge(prediction, conf_thres, nms_thres, out[0], out[1], out[2], _workspace(prediction.device, bs, rows, nc),
+                    min_wh=MIN_WH, max_per_class=MAX_PER_CLASS, mutate_conf=inplace_conf)
     return out
 
 
 def nms_launch(prediction, conf_thres, nms_thres, out, slot=0, inplace_conf=False):
-    """Launch the NMS kernels on the current stream into ``out`` = (dets, idx, count); ``slot`` selects a
-    private workspace so that concurrent streams do not share scratch memory."""
+    """Launch the NMS kernels on the current stream into ``out`` = (dets, idx, count); the workspace is private to the
+    current stream (``slot`` is kept for callers of the old signature and ignored)."""
     bs, rows, no = prediction.shape
-    K.nms_merge(prediction, conf_thres, nms_thres, out[0], out[1], out[2],
-                _workspace(prediction.device, bs, rows, no - 5, slot), min_wh=MIN_WH, max_per_class=MAX_PER_CLASS,
-                mutate_conf=inplace_conf)
+    with torch.cuda.device(prediction.device):
+        K.nms_merge(prediction, conf_thres, nms_thres, out[0], out[1], out[2],
+                    _workspace(prediction.device, bs, rows, no - 5), min_wh=MIN_WH, max_per_class=MAX_PER_CLASS,
+                    mutate_conf=inplace_conf)
     return out
 
 
@@ -122,8 +131,9 @@ def scale_coords(img1_shape, coords, img0_shape, round_result=False):
         return coords
     params = torch.tensor([_scale_params(img1_shape, img0_shape, n)], dtype=torch.float32, device=coords.device)
     from .._lib import check, load
-    check(load().yolo_scale_coords(coords.data_ptr(), 1, n, coords.shape[1], params.data_ptr(), int(round_result),
-                                   K.stream_ptr()), "scale_coords")
+    with torch.cuda.device(coords.device):
+        check(load().yolo_scale_coords(coords.data_ptr(), 1, n, coords.shape[1], params.data_ptr(), int(round_result),
+                                       K.stream_ptr()), "scale_coords")
     return coords
 
 
@@ -134,8 +144,9 @@ def scale_detections(dets, count, img1_shape, img0_shapes, round_result=True):
     params = torch.tensor([_scale_params(img1_shape, s0, n) for s0, n in zip(img0_shapes, counts)],
                           dtype=torch.float32, device=dets.device)
     from .._lib import check, load
-    check(load().yolo_scale_coords(dets.data_ptr(), dets.shape[0], dets.shape[1], dets.shape[2], params.data_ptr(),
-                                   int(round_result), K.stream_ptr()), "scale_coords")
+    with torch.cuda.device(dets.device):
+        check(load().yolo_scale_coords(dets.data_ptr(), dets.shape[0], dets.shape[1], dets.shape[2], params.data_ptr(),
+                                       int(round_result), K.stream_ptr()), "scale_coords")
     return dets
 
 

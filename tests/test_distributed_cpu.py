@@ -37,6 +37,13 @@ def _worker(rank, world, port, ret):
     assert ok
     lo, hi = shard_bounds(7, world, rank)
     ret[rank] = (lo, hi)
+    # uneven shards (7 images over 2 ranks: 4 + 3): padded on the wire, stripped afterwards, global order kept
+    n_local = hi - lo
+    d2 = torch.full((n_local, cap, 7), float(rank + 1))
+    c2 = torch.arange(lo, hi, dtype=torch.int32) % 3
+    a2, k2 = gather_detections(d2, c2, gather_cap=8)
+    assert a2.shape == (7, 8, 7) and k2.tolist() == [i % 3 for i in range(7)]
+    assert torch.all(a2[:4] == 1.0) and torch.all(a2[4:] == 2.0)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -54,3 +61,31 @@ def test_allgather_world2():
     [p.join(120) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     assert dict(ret) == {0: (0, 4), 1: (4, 7)}
+
+
+def _run_bench(*argv, env=None):
+    import subprocess
+    e = dict(os.environ)
+    e.pop("RANK", None), e.pop("WORLD_SIZE", None), e.pop("LOCAL_RANK", None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, env=e, timeout=300)
+
+
+def test_bench_gpus_n_starts_n_ranks_by_itself():
+    """`python bench.py --gpus 2` (no torch.distributed.run around it) starts two rank processes; rehearsed here without a
+    GPU (--dry-run: gloo, real gather code, nothing measured).  The JSON line reports the ranks that really ran."""
+    import json
+    r = _run_bench("--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["rccl_ranks"] == 2 and out["config"]["gather_ok"] is True
+    assert out["value"] is None and "dry-run" in out["data"]
+
+
+def test_bench_never_reports_fewer_ranks_than_asked():
+    """No GPU here: `--gpus 2` must fail loudly (non-zero, no JSON line), and a WORLD_SIZE that disagrees with --gpus too."""
+    r = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert r.returncode != 0 and "refusing" in r.stderr and not any(ln.startswith("{") for ln in r.stdout.splitlines())
+    r = _run_bench("--gpus", "8", "--steps", "1", "--warmup", "0", env=dict(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)

@@ -1081,3 +1081,397 @@ def test_preprocess_batch_vs_oracle():
     with torch.no_grad():
         io, _ = model(got)
     assert io.shape[0] == len(imgs) and bool(torch.isfinite(io).all())
+
+
+# ------------------------------------------------------------------------------------------------
+# fp32 reference-precision mode (csrc/conv_f32.hip) and the end-to-end detection-set checks
+F32_CONV_CASES = [
+    # n, h, w, cin, cout, k, stride, act, residual, aux, upsample
+    (2, 16, 16, 8, 32, 3, 1, "leaky", False, False, False),       # first-layer shape (3 -> 8 padded channels)
+    (2, 20, 20, 64, 128, 3, 1, "leaky", True, True, False),       # residual + pre-add copy
+    (1, 33, 29, 32, 64, 3, 2, "leaky", False, False, False),      # odd size, stride 2
+    (3, 13, 13, 256, 255, 1, 1, "none", False, False, False),     # detection head: 255 couts
+    (2, 10, 10, 128, 64, 1, 1, "leaky", False, False, True),      # 2x nearest upsample on store
+    (1, 9, 9, 1024, 512, 1, 1, "leaky", False, False, False),     # long K
+    (1, 40, 24, 20, 36, 3, 1, "relu6", False, False, False),      # channel counts that are only multiples of 4
+]
+
+
+@pytest.mark.parametrize("case", F32_CONV_CASES, ids=lambda c: "n%d_%dx%d_c%d-%d_k%d_s%d_%s_r%d_a%d_u%d" % tuple(int(v) if not isinstance(v, str) else v for v in c))
+def test_conv_f32_kernel(case):
+    """yolo_conv2d_f32_fwd against torch's fp32 conv on the SAME fp32 operands: only the summation order differs."""
+    from pytorch_yolo_amd import kernels as K
+    from pytorch_yolo_amd._lib import ACT_LEAKY01, ACT_NONE, ACT_RELU6, DT_F32
+    n, h, w, cin, cout, k, stride, act, use_res, use_aux, up = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    pad = (k - 1) // 2
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    res = torch.randn(n, cout, ho, wo, generator=g) if use_res else None
+    in_ct, in_co = cin + 8, 4
+    xin = torch.zeros(n, h, w, in_ct, dtype=torch.float32, device=DEV)
+    xin[..., in_co:in_co + cin] = x.permute(0, 2, 3, 1).to(DEV)
+    oh, ow = (2 * ho, 2 * wo) if up else (ho, wo)
+    out_ct, out_co = K.roundup(cout, 4) + 8, 4
+    y = torch.full((n, oh, ow, out_ct), -77.0, dtype=torch.float32, device=DEV)
+    aux = torch.full((n, ho, wo, K.roundup(cout, 4) + 4), -77.0, dtype=torch.float32, device=DEV) if use_aux else None
+    rin = res.permute(0, 2, 3, 1).contiguous().to(DEV) if use_res else None
+    wp, bp, kpad, cout_pad = K.pack_conv_weight_f32(wt, bias, cin)
+    d = K.conv_desc(n=n, h=h, w=w, cin=cin, in_c_total=in_ct, in_c_offset=in_co, cout=cout, out_c_total=out_ct,
+                    out_c_offset=out_co, ksize=k, stride=stride,
+                    act={"leaky": ACT_LEAKY01, "none": ACT_NONE, "relu6": ACT_RELU6}[act], kpad=kpad, cout_pad=cout_pad,
+                    upsample2x=int(up), out_dtype=DT_F32, res=(cout, 0) if use_res else (0, 0),
+                    aux=(aux.shape[-1], 4) if use_aux else (0, 0))
+    K.conv2d_f32(xin, wp.to(DEV), bp.to(DEV), y, d, residual=rin, y_preadd=aux)
+    torch.cuda.synchronize()
+    ref = F.conv2d(x, wt, bias, stride=stride, padding=pad)
+    ref = {"leaky": lambda t: F.leaky_relu(t, 0.1), "none": lambda t: t, "relu6": F.relu6}[act](ref)
+    pre = ref
+    if use_res:
+        ref = ref + res
+    if up:
+        ref = F.interpolate(ref, scale_factor=2, mode="nearest")
+    got = _nchw(y[..., out_co:out_co + cout])
+    torch.testing.assert_close(got, ref, rtol=2e-5, atol=2e-5)
+    assert torch.all(y[..., :out_co] == -77.0) and torch.all(y[..., out_co + cout:] == -77.0)
+    if use_aux:
+        torch.testing.assert_close(_nchw(aux[..., 4:4 + cout]), pre, rtol=2e-5, atol=2e-5)
+        assert torch.all(aux[..., :4] == -77.0)
+
+
+def _assert_fp32_close(io, io_ref, tag, box_atol=2e-3, box_rtol=2e-5, score_atol=2e-5):
+    """fp32 mode vs the fp32 reference: only BN folding and summation order differ."""
+    io, io_ref = io.double(), io_ref.double()
+    box = (io[..., :4] - io_ref[..., :4]).abs()
+    score = (io[..., 4:] - io_ref[..., 4:]).abs()
+    print(f"[{tag}] fp32 mode vs fp32 reference: max box abs {box.max().item():.6f} px, max score abs {score.max().item():.2e}")
+    assert bool((box <= box_atol + box_rtol * io_ref[..., :4].abs()).all()), f"{tag}: boxes differ by {box.max().item()} px"
+    assert score.max().item() <= score_atol, f"{tag}: scores differ by {score.max().item()}"
+
+
+@pytest.mark.parametrize("name", list(C.MODEL_CASES))
+def test_fp32_mode_small_models_vs_reference_golden(name):
+    """model.precision = 'fp32': io / p against the REFERENCE's golden tensors at fp32 accuracy."""
+    case = C.MODEL_CASES[name]
+    model, sd, x = build_case(case)
+    model.precision = "fp32"
+    model = model.to(DEV)
+    with torch.no_grad():
+        io, p = model(x.to(DEV))
+    g = load_golden("model_" + name)
+    _assert_fp32_close(io.cpu(), torch.from_numpy(g["io"]), name + "/fp32")
+    for k, t in enumerate(p):
+        torch.testing.assert_close(t.cpu(), torch.from_numpy(g[f"p{k}"]), rtol=2e-4, atol=2e-4)
+    # and the bf16 plan of the same model is a different plan (the cache is keyed by precision)
+    model.precision = "bf16"
+    with torch.no_grad():
+        io_b, _ = model(x.to(DEV))
+    assert not torch.equal(io_b, io)
+
+
+def _iou_matrix(a, b):
+    """pairwise IoU of xyxy boxes a [n,4], b [m,4] (numpy float64)."""
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    x1 = np.maximum(a[:, None, 0], b[None, :, 0]); y1 = np.maximum(a[:, None, 1], b[None, :, 1])
+    x2 = np.minimum(a[:, None, 2], b[None, :, 2]); y2 = np.minimum(a[:, None, 3], b[None, :, 3])
+    inter = np.clip(x2 - x1, 0, None) * np.clip(y2 - y1, 0, None)
+    aa = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]); bb = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    return inter / np.maximum(aa[:, None] + bb[None, :] - inter, 1e-12)
+
+
+def _unmatched(a, b, iou_min, conf_tol):
+    """rows of a [n,7] without a partner in b [m,7] of the same class with IoU >= iou_min and |dconf| <= conf_tol."""
+    if len(a) == 0:
+        return []
+    if len(b) == 0:
+        return list(range(len(a)))
+    iou = _iou_matrix(a[:, :4], b[:, :4])
+    ok = (iou >= iou_min) & (a[:, None, 6] == b[None, :, 6]) & (np.abs(a[:, None, 4] - b[None, :, 4]) <= conf_tol)
+    return [i for i in range(len(a)) if not ok[i].any()]
+
+
+def _stable_detections(pred_np, conf, iou, eps_conf, eps_iou, eps_cls):
+    """SURVEY 7's guard band, made operational.  Returns (all detections, those outside the guard band) of ``pred`` under
+    the oracle MERGE-NMS.  A detection is INSIDE the band (excluded from the comparison) when
+      * its pivot row does not survive every perturbation of the two thresholds by +-eps (candidates within eps of
+        conf_thres; merge groups whose membership hinges on an IoU within eps of nms_thres), or
+      * its pivot row's two best class scores are within eps_cls of each other (the arg-max class can flip)."""
+    from oracle import nms as onms
+    dets, kept = onms.nms_image(pred_np.copy(), conf, iou)
+    if dets is None:
+        return np.zeros((0, 7), np.float32), np.zeros((0, 7), np.float32)
+    stable = set(kept.tolist())
+    for dc in (-eps_conf, eps_conf):
+        for di in (-eps_iou, eps_iou):
+            d2, k2 = onms.nms_image(pred_np.copy(), conf + dc, iou + di)
+            stable &= set(() if d2 is None else k2.tolist())
+    cls = np.sort(pred_np[kept, 5:], axis=1)
+    gap_ok = (cls[:, -1] - cls[:, -2] > eps_cls) if cls.shape[1] > 1 else np.ones(len(kept), bool)
+    mask = np.array([k in stable for k in kept.tolist()], bool) & gap_ok
+    return dets, dets[mask]
+
+
+GUARD = dict(eps_conf=0.03, eps_iou=0.05, eps_cls=0.03)   # guard band around conf_thres / nms_thres / class arg-max (SURVEY 7)
+MATCH = dict(iou_min=0.8, conf_tol=0.06)                  # a partner: same class, IoU >= 0.8, |dconf| <= 0.06
+# MERGE replaces every kept box by the confidence-weighted mean of ALL boxes it suppresses (utils.py:266-275): with synthetic
+# weights each class has piles of ~20..100 overlapping candidates, and which pile a borderline box joins moves the mean by
+# more than the bf16 drift itself.  Threshold perturbation cannot predict that, so the set comparison is a rate: at least
+# MATCH_RATE of the detections outside the guard band have a partner (measured >= 0.95), and EVERY confident one does.
+MATCH_RATE = 0.92
+CONFIDENT = 0.5
+
+
+@pytest.mark.parametrize("name", list(C.FULL_CASES))
+def test_full_size_detection_sets_vs_reference(name):
+    """End to end on the BASELINE configs at full size, against the reference's own NMS output stored in the golden
+    (nms_dets_0 / nms_kept_0, tests/golden/make_golden.py):
+      * fp32 mode: the kept-index set IS the reference's, class equal, conf / class_conf within 2e-5, boxes within 1e-2 px;
+      * bf16 mode: outside the guard band (_stable_detections) reference and bf16 detections pair up (same class,
+        IoU >= 0.8, |dconf| <= 0.06) at a rate >= MATCH_RATE in both directions, and without exception above conf 0.5."""
+    from oracle import nms as onms
+    from pytorch_yolo_amd.utils.utils import non_max_suppression
+    case = C.FULL_CASES[name]
+    model, sd, x = build_case(case)
+    g = load_golden("full_" + name)
+    ref_dets, ref_kept = g["nms_dets_0"], g["nms_kept_0"]
+    io_ref, _ = oracle_forward(case, sd, x)                     # the reference's arithmetic (bit-equal in the build container; another
+    odets, okept = onms.non_max_suppression(io_ref.numpy().copy(), **C.NMS_FULL)   # host CPU sums in another order: 1e-6 relative)
+    assert np.array_equal(okept[0], ref_kept) and np.allclose(odets[0], ref_dets, rtol=1e-5, atol=1e-3)   # ties this oracle run to the golden
+    model = model.to(DEV)
+    # ---- fp32 mode
+    model.precision = "fp32"
+    with torch.no_grad():
+        io32, _ = model(x.to(DEV))
+    _assert_fp32_close(io32.cpu()[:, g["rows"]], torch.from_numpy(g["io_rows"]), name + "/fp32 rows")
+    _assert_fp32_close(io32.cpu(), io_ref, name + "/fp32 all rows")
+    dets32, idx32 = non_max_suppression(io32, with_indices=True, **C.NMS_FULL)
+    d32, k32 = dets32[0].cpu().numpy(), idx32[0].cpu().numpy()
+    print(f"[{name}] fp32 mode: {len(d32)} detections, reference {len(ref_dets)}")
+    assert np.array_equal(k32, ref_kept), "fp32 mode: kept-index set differs from the reference's"
+    assert np.array_equal(d32[:, 6], ref_dets[:, 6])
+    np.testing.assert_allclose(d32[:, 4:6], ref_dets[:, 4:6], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(d32[:, :4], ref_dets[:, :4], rtol=0, atol=1e-2)
+    # ---- bf16 mode with the guard band
+    model.precision = "bf16"
+    with torch.no_grad():
+        io16, _ = model(x.to(DEV))
+    dets16, _ = non_max_suppression(io16, with_indices=True, **C.NMS_FULL)
+    d16 = dets16[0].cpu().numpy()
+    ref_all, ref_stable = _stable_detections(io_ref[0].numpy(), C.NMS_FULL["conf_thres"], C.NMS_FULL["nms_thres"], **GUARD)
+    hip_all, hip_stable = _stable_detections(io16[0].cpu().numpy(), C.NMS_FULL["conf_thres"], C.NMS_FULL["nms_thres"], **GUARD)
+    assert np.array_equal(hip_all, d16)                            # (the device NMS is the oracle NMS, bit for bit)
+    miss_ref = _unmatched(ref_stable, d16, **MATCH)
+    miss_hip = _unmatched(hip_stable, ref_all, **MATCH)
+    print(f"[{name}] bf16 mode: {len(d16)} detections ({len(hip_stable)} outside the guard band), reference {len(ref_all)} "
+          f"({len(ref_stable)} outside); unmatched: reference {len(miss_ref)}, bf16 {len(miss_hip)}")
+    for tag, rows, pool in (("reference", ref_stable[miss_ref], d16), ("bf16", hip_stable[miss_hip], ref_all)):
+        for r in rows:
+            same = pool[pool[:, 6] == r[6]]
+            best = _iou_matrix(r[None, :4], same[:, :4]).max() if len(same) else 0.0
+            print(f"   {tag} detection without a partner: cls {int(r[6])} conf {r[4]:.3f} box {np.round(r[:4], 1)} best same-class IoU {best:.2f}")
+    assert len(ref_stable) >= 20 and len(hip_stable) >= 20, "the comparison is vacuous"
+    assert len(miss_ref) <= (1 - MATCH_RATE) * len(ref_stable) and len(miss_hip) <= (1 - MATCH_RATE) * len(hip_stable)
+    assert not any(ref_stable[i][4] >= CONFIDENT for i in miss_ref) and not any(hip_stable[i][4] >= CONFIDENT for i in miss_hip)
+    assert abs(len(d16) - len(ref_all)) <= 0.1 * len(ref_all)
+
+
+def test_bf16_path_within_its_rounding_budget():
+    """SPP-640 at full size: the distance of the HIP bf16 forward to the fp32 reference must be the distance that bf16
+    operand rounding alone produces — the oracle re-run under the fast path's rounding policy (oracle/policy.py: BN folded
+    in fp32, bf16 conv operands, fp32 accumulate, bf16 residual stream) is the budget, per head, with 25 % head-room.
+    profiles/r02_drift_trace_spp640.md holds the same comparison launch by launch.  A mis-wired layer, a wrong pad or a
+    dropped tap is an error the budget does not contain."""
+    from oracle import models as om
+    from oracle.policy import run_policy
+    case = C.FULL_CASES["spp_640"]
+    model, sd, x = build_case(case)
+    io_pol, p_pol = run_policy(om.spp_forward, sd, x, C.SPP_ANCHORS, 80, policy="bf16")
+    io_ref, p_ref = oracle_forward(case, sd, x)
+    model = model.to(DEV)
+    with torch.no_grad():
+        io, p = model(x.to(DEV))
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    for k in range(3):
+        got, budget = rel(p[k].cpu(), p_ref[k]), rel(p_pol[k], p_ref[k])
+        mx, mx_b = float((p[k].cpu() - p_ref[k]).abs().max()), float((p_pol[k] - p_ref[k]).abs().max())
+        print(f"[spp_640] head {k} raw logits vs fp32 reference: rel rms {got:.5f} (budget {budget:.5f}), max abs {mx:.3f} (budget {mx_b:.3f})")
+        assert got <= 1.25 * budget + 2e-4, f"head {k}: error {got} beyond the bf16 rounding budget {budget}"
+        assert mx <= 2.0 * mx_b + 0.05
+    rms = lambda a, b: float((a[..., 4:].double() - b[..., 4:].double()).pow(2).mean().sqrt())
+    got, budget = rms(io.cpu(), io_ref), rms(io_pol, io_ref)
+    print(f"[spp_640] scores vs fp32 reference: rms {got:.6f} (budget {budget:.6f})")
+    assert got <= 1.25 * budget + 1e-4
+    # the stated end-to-end bound of the bf16 mode on this configuration: raw head logits within 1.0 of the reference
+    # (measured 0.71; logit std is 25..40 here), hence scores within 0.25 (the sigmoid's slope is <= 1/4)
+    _assert_model_close(io.cpu(), io_ref, "spp_640 HIP bf16 vs fp32 reference", score_max=0.25, score_rms=1e-2, box_rel_tol=0.02)
+
+
+def _seeded_batch(n, hw, first_seed=0):
+    """n images, image i = synth_images(1, hw, hw, first_seed + i): image 0 is the golden's image."""
+    from pytorch_yolo_amd.utils.synthetic import synth_images
+    return torch.cat([synth_images(1, hw, hw, first_seed + i) for i in range(n)], 0)
+
+
+def test_headline_config_bs32_two_streams():
+    """The configuration bench.py times — YOLOv3-SPP 640x640, 32 images, two sub-batch streams of 16 — end to end:
+    image 0 against the reference golden (same bounds as the bs=1 test), the two-stream run bit-equal to one-stream runs
+    of its halves, sampled images against the fp32 oracle, detect() against the oracle NMS."""
+    from oracle import models as om
+    from oracle import nms as onms
+    case = C.FULL_CASES["spp_640"]
+    model, sd, _ = build_case(case)
+    g = load_golden("full_spp_640")
+    x = _seeded_batch(32, 640)
+    model = model.to(DEV)
+    xd = x.to(DEV)
+    with torch.no_grad():
+        model.n_streams = 2
+        assert type(model.plan_for(xd)).__name__ == "StreamedPlan"
+        io, p = model(xd)
+        io_c = io.cpu()
+        _assert_model_close(io_c[:1][:, g["rows"]], torch.from_numpy(g["io_rows"]), "spp_640x32 image 0 / golden rows", score_max=0.25, score_rms=1e-2)
+        model.n_streams = 1
+        for half in (0, 1):
+            io_h, _ = model(xd[16 * half:16 * half + 16])
+            assert torch.equal(io_h, io[16 * half:16 * half + 16]), "two-stream run differs from the one-stream run of its half"
+        for i in (0, 13, 31):
+            io_ref, _ = om.spp_forward(sd, x[i:i + 1], C.SPP_ANCHORS, 80)
+            _assert_model_close(io_c[i:i + 1], io_ref, f"spp_640x32 image {i} vs fp32 oracle", score_max=0.25, score_rms=1e-2)
+        model.n_streams = 2
+        dets = model.detect(xd, **C.NMS_FULL)
+    odets, _ = onms.non_max_suppression(io_c.numpy().copy(), **C.NMS_FULL)
+    for b in range(32):
+        assert (dets[b] is None) == (odets[b] is None)
+        if odets[b] is not None:
+            assert np.array_equal(dets[b].cpu().numpy(), odets[b])
+    n = [0 if d is None else len(d) for d in dets]
+    print(f"[spp_640x32] detections per image: min {min(n)}, mean {sum(n) / 32:.1f}, max {max(n)}")
+    assert min(n) > 0
+
+
+def test_secondary_configs_at_bench_batch_sizes():
+    """YOLOv3-tiny 416x416 bs=32 (two streams of 16) and YOLOv3-tiny/MobileNetV2 416x416 bs=64 (two streams of 32): sampled
+    images against the fp32 oracle with the small-model bounds."""
+    from oracle import models as om
+    from pytorch_yolo_amd import YOLOv3TinyMobile
+    from pytorch_yolo_amd.utils.synthetic import synth_state_dict
+    case = C.FULL_CASES["tiny_416"]
+    model, sd, _ = build_case(case)
+    x = _seeded_batch(32, 416)
+    model = model.to(DEV)
+    with torch.no_grad():
+        io, _ = model(x.to(DEV))
+        assert type(model.plan_for(x.to(DEV))).__name__ == "StreamedPlan"
+        g = load_golden("full_tiny_416")
+        _assert_model_close(io.cpu()[:1][:, g["rows"]], torch.from_numpy(g["io_rows"]), "tiny_416x32 image 0 / golden rows")
+        for i in (7, 31):
+            io_ref, _ = om.tiny_forward(sd, x[i:i + 1], C.TINY_ANCHORS, 80)
+            _assert_model_close(io.cpu()[i:i + 1], io_ref, f"tiny_416x32 image {i}")
+    mob = YOLOv3TinyMobile(n_class=80).eval()
+    sdm = synth_state_dict(mob.state_dict(), 1234, n_class=80)
+    mob.load_state_dict(sdm)
+    mob = mob.to(DEV)
+    xm = _seeded_batch(64, 416, first_seed=100)
+    with torch.no_grad():
+        io, _ = mob(xm.to(DEV))
+        for i in (0, 40, 63):
+            io_ref, _ = om.tiny_mobile_forward(sdm, xm[i:i + 1], om.TINY_ANCHORS, 80)
+            _assert_model_close(io.cpu()[i:i + 1], io_ref, f"mobile_416x64 image {i}", score_max=3e-2, score_rms=4e-3)
+
+
+# ------------------------------------------------------------------------------------------------
+# boundary hygiene
+def test_integration_md_stub_b_runs_verbatim():
+    """INTEGRATION.md section B (the hand-written ctypes binding a reference maintainer would add) is executed exactly as
+    printed and its two functions are checked against the oracle: decode (io rtol 2e-6, p exact) and NMS (bit-exact)."""
+    import os
+    import re
+    import types
+    from oracle import blocks as ob
+    from oracle import nms as onms
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    section = text[text.index("## B."):text.index("## Contract reminders")]
+    code = re.search(r"```python\n(.*?)```", section, re.S).group(1)
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(root)                                             # the stub opens the library by its in-tree relative path
+    try:
+        exec(compile(code, "INTEGRATION.md#B", "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    nc, ny, nx, img = 80, 13, 17, 544
+    anchors = torch.tensor(C.TINY_ANCHORS[1])
+    layer = types.SimpleNamespace(n_classes=nc, anchors=anchors)
+    g = torch.Generator().manual_seed(9)
+    p_raw = torch.randn(2, 3 * (5 + nc), ny, nx, generator=g)
+    io, pp = ns["yolo_layer_forward"](layer, p_raw.to(DEV), img)
+    torch.cuda.synchronize()
+    io_ref, p_ref = ob.yolo_decode(p_raw, C.TINY_ANCHORS[1], nc, img)
+    assert torch.equal(pp.cpu(), p_ref)
+    torch.testing.assert_close(io.cpu(), io_ref, rtol=2e-6, atol=1e-5)
+    pred, conf, iou = C.nms_case_inputs("nms_mid_nc80")
+    work = torch.from_numpy(pred.copy()).to(DEV)
+    out = ns["non_max_suppression"](work, conf, iou)
+    torch.cuda.synchronize()
+    ref = pred.copy()
+    odets, _ = onms.non_max_suppression(ref, conf, iou)
+    for b in range(pred.shape[0]):
+        assert (out[b] is None) == (odets[b] is None)
+        if odets[b] is not None:
+            assert np.array_equal(out[b].cpu().numpy(), odets[b])
+    assert np.array_equal(work.cpu().numpy()[..., 4], ref[..., 4], equal_nan=True)     # mutate_conf=1: the reference's side effect
+
+
+def test_plan_cache_follows_weight_changes():
+    """The cached plan holds packed copies of the weights: any change of a parameter — through a SUB-module's
+    load_state_dict, an in-place copy, a block-level fuse() — must rebuild it (stale weights were used silently)."""
+    case = C.MODEL_CASES["tiny_small"]
+    model, sd, x = build_case(case)
+    model = model.to(DEV)
+    xd = x.to(DEV)
+    with torch.no_grad():
+        io0, _ = model(xd)
+        plan0 = model.plan_for(xd)
+        assert model.plan_for(xd) is plan0                                   # unchanged weights: cache hit
+        blk = model.sequence_1.conv1
+        new = {k: v * 1.5 for k, v in blk.state_dict().items() if k.endswith("conv.weight")}
+        blk.load_state_dict({**blk.state_dict(), **new})                     # sub-module load: the top-level hook never sees it
+        io1, _ = model(xd)
+        assert model.plan_for(xd) is not plan0 and not torch.equal(io0, io1)
+        fresh, _, _ = build_case(case)
+        fresh.sequence_1.conv1.load_state_dict({**fresh.sequence_1.conv1.state_dict(), **{k: v.cpu() for k, v in new.items()}})
+        io1_ref, _ = fresh.to(DEV)(xd)
+        assert torch.equal(io1, io1_ref)
+        plan1 = model.plan_for(xd)
+        model.sequence_2.conv7.sequence.batch_norm.bias.data.add_(0.25)      # in-place edit of one buffer-like parameter
+        io2, _ = model(xd)
+        assert model.plan_for(xd) is not plan1 and not torch.equal(io1, io2)
+        plan2 = model.plan_for(xd)
+        model.sequence_2.conv8.fuse()                                        # block-level fuse: same function, new parameters
+        io3, _ = model(xd)
+        assert model.plan_for(xd) is not plan2
+        _assert_model_close(io3.cpu(), io2.cpu(), "after block-level fuse", score_max=2e-3, score_rms=2e-4)
+    for i in range(12):                                                      # the per-model cache is bounded
+        with torch.no_grad():
+            model(torch.zeros(1, 3, 32 + 32 * i, 64, device=DEV))
+    from pytorch_yolo_amd.models.yolo_base import MAX_CACHED_PLANS
+    assert len(model._plans) <= MAX_CACHED_PLANS
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs a second GPU")
+def test_model_on_a_non_current_device():
+    """Model and input on cuda:1 while the current device is cuda:0 (launches landed on GPU 0)."""
+    case = C.MODEL_CASES["tiny_small"]
+    model, sd, x = build_case(case)
+    io_ref, _ = oracle_forward(case, sd, x)
+    torch.cuda.set_device(0)
+    model = model.to("cuda:1")
+    with torch.no_grad():
+        io, _ = model(x.to("cuda:1"))
+        dets = model.detect(x.to("cuda:1"), 0.01, 0.5)
+    assert io.device.index == 1 and torch.cuda.current_device() == 0
+    _assert_model_close(io.cpu(), io_ref, "tiny_small on cuda:1")
+    assert all(d is None or d.device.index == 1 for d in dets)
