@@ -39,6 +39,9 @@ enum { YOLO_DT_BF16 = 0, YOLO_DT_F32 = 1 };
 
 YOLO_API const char* yolo_last_error(void);
 YOLO_API int yolo_abi_version(void);
+/* Tuning / A-B hook (process-wide, not part of the numerics contract): overrides what the environment variables
+ * YOLO_CONV_VARIANT (knob 0), YOLO_CONV_DEBUG (knob 1) and YOLO_CONV_PP (knob 2) set at load time.  Returns the old value. */
+YOLO_API int yolo_set_tuning(int knob, int value);
 
 /* ---- input packing: the `imgs.to(device)` + first-layer layout step (utils/utils.py:374) -----
  * x: f32 NCHW [n,c,h,w]  ->  y: bf16 NHWC [n,h,w,c_pad] (channels c..c_pad-1 zero). */

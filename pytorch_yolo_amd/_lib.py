@@ -49,6 +49,7 @@ class YoloMbconvDesc(C.Structure):
 SIGNATURES = {
     "yolo_last_error": (C.c_char_p, []),
     "yolo_abi_version": (C.c_int, []),
+    "yolo_set_tuning": (C.c_int, [C.c_int, C.c_int]),
     "yolo_pack_input_nchw_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
     "yolo_conv2d_fwd": (C.c_int, [C.c_void_p] * 6 + [C.POINTER(YoloConvDesc), C.c_void_p]),
     "yolo_conv2d_splitk_plan": (C.c_int, [C.POINTER(YoloConvDesc), C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t),

@@ -24,6 +24,7 @@ SOURCES = {
     "conv_mbconv.hip": [],
     "conv_small.hip": [],
     "conv_f32.hip": ["-ffp-contract=off"],
+    "conv_pp.hip": [],
     "pointwise.hip": [],
     "preprocess.hip": ["-ffp-contract=off"],
     "nms.hip": ["-ffp-contract=off"],

@@ -594,6 +594,7 @@ int launch_cfg(const ConvArgs& a, hipStream_t s) {
 
 int conv_variant_override = -1;
 int conv_debug_flags = 0;   // tuning hook (YOLO_CONV_VARIANT), see yolo_conv2d_launch
+int conv_pp_mask = 0;       // YOLO_CONV_PP: which tile rules hand their layers to the ping-pong kernel (conv_pp.hip)
 
 // split-K request of the current yolo_conv2d_splitk_fwd call (consumed by conv2d_launch_ex)
 struct SplitK {
@@ -626,6 +627,25 @@ void splitk_shape(const YoloConvDesc& d, bool has_res_or_aux_views_ok, long* til
 static int conv2d_launch_ex(const void* x, const void* w, const float* bias, const void* res, void* y, void* y_aux,
                             const YoloConvDesc* dp, const HeadDecodeArgs* hd, hipStream_t s);
 
+static bool read_conv_env() {
+  static const bool done = [] {
+    if (const char* e = getenv("YOLO_CONV_VARIANT")) conv_variant_override = atoi(e);
+    if (const char* e = getenv("YOLO_CONV_DEBUG")) conv_debug_flags = atoi(e);
+    if (const char* e = getenv("YOLO_CONV_PP")) conv_pp_mask = atoi(e);
+    return true;
+  }();
+  return done;
+}
+
+extern "C" int yolo_set_tuning(int knob, int value) {
+  read_conv_env();
+  int* const slot = knob == 0 ? &conv_variant_override : knob == 1 ? &conv_debug_flags : knob == 2 ? &conv_pp_mask : nullptr;
+  YOLO_REQUIRE(slot, "set_tuning: unknown knob %d", knob);
+  const int old = *slot;
+  *slot = value;
+  return old;
+}
+
 int yolo_conv2d_launch(const void* x, const void* w, const float* bias, const void* res, void* y, void* y_aux,
                        const YoloConvDesc* dp, hipStream_t s) {
   return conv2d_launch_ex(x, w, bias, res, y, y_aux, dp, nullptr, s);
@@ -634,12 +654,7 @@ int yolo_conv2d_launch(const void* x, const void* w, const float* bias, const vo
 static int conv2d_launch_ex(const void* x, const void* w, const float* bias, const void* res, void* y, void* y_aux,
                             const YoloConvDesc* dp, const HeadDecodeArgs* hd, hipStream_t s) {
   YOLO_REQUIRE(x && w && bias && (y || hd) && dp, "conv: null pointer");
-  static const bool env_read = [] {
-    if (const char* e = getenv("YOLO_CONV_VARIANT")) conv_variant_override = atoi(e);
-    if (const char* e = getenv("YOLO_CONV_DEBUG")) conv_debug_flags = atoi(e);
-    return true;
-  }();
-  (void)env_read;
+  read_conv_env();
   const YoloConvDesc& d = *dp;
   YOLO_REQUIRE(d.ksize == 1 || d.ksize == 3, "conv: ksize %d unsupported (1 or 3)", d.ksize);
   YOLO_REQUIRE(d.stride == 1 || d.stride == 2, "conv: stride %d unsupported", d.stride);
@@ -691,7 +706,7 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
   const bool epi = d.out_dtype == YOLO_DT_BF16 && d.cout % 32 == 0 && d.out_c_offset % 8 == 0 && d.out_c_total % 8 == 0 &&
                    (!res || (d.res_c_offset % 8 == 0 && d.res_c_total % 8 == 0)) &&
                    (!y_aux || (d.aux_c_offset % 8 == 0 && d.aux_c_total % 8 == 0)) && !(conv_debug_flags & 16);
-  if (epi && !(conv_debug_flags & 32) && conv_variant_override < 0) {   // large 3x3/s1 maps: halo-staged kernel
+  if (epi && !(conv_debug_flags & 32) && conv_variant_override < 0 && !(conv_pp_mask & 8)) {   // large 3x3/s1 maps: halo-staged kernel
     a.n_tiles = 0;
     const int rc = launch_halo3x3(a, s);
     if (rc != 1) return rc;
@@ -727,6 +742,16 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
   // 16x16x32 MFMA mainloop (same LDS traffic and cycles per FLOP as 32x32x16; the chip holds a higher clock on
   // it: +2..3 % measured on every shape).  YOLO_CONV_DEBUG bit 2048 falls back to 32x32x16.
   if (epi && !(conv_debug_flags & 2048)) {
+    if (conv_pp_mask && a.splits <= 1) {      // ping-pong main loop (conv_pp.hip): bit 1 the 256x256 layers, bit 2 the 128x256 ones,
+      int which = 0;                           // bit 4: every layer either tile shape fits
+      if ((conv_pp_mask & 1) && pick == 5) which = 1;
+      if ((conv_pp_mask & 2) && pick == 12) which = 2;
+      if ((conv_pp_mask & 4) && d.cout % 256 == 0) which = ((M + 255) / 256) * (d.cout / 256) >= 160 ? 1 : 2;
+      if (which) {
+        const int rc = launch_pingpong(a, which, s);
+        if (rc != 1) return rc;
+      }
+    }
     switch (pick) {
       case 5:
         // 16 waves (64x64 each) instead of 8 (64x128): four waves per SIMD hide the LDS-DMA issue stalls of one another

@@ -141,8 +141,10 @@ class YOLOBase(nn.Module):
 
     def _fingerprint(self):
         """Cheap identity of the weights a cached plan was packed from: (structure epoch, storage address and in-place
-        version counter of every parameter / buffer).  It moves on sub-module load_state_dict / fuse, p.data.copy_,
-        nn.init.*, optimizer steps, .to() — everything that would otherwise leave a plan with stale packed weights."""
+        version counter of every parameter / buffer).  It moves on sub-module load_state_dict / fuse, in-place edits of a
+        parameter (p.copy_, nn.init.*, optimizer steps), .to() and p.data = new — what would otherwise leave a plan with
+        stale packed weights.  NOT seen: in-place writes through ``p.data`` (p.data.copy_ / p.data.add_ bypass torch's
+        version counters by design); call ``model.invalidate()`` after such an edit."""
         if self.__dict__.get("_tensors") is None or self.__dict__.get("_epoch_seen") != _STRUCT_EPOCH[0]:
             self._epoch_seen = _STRUCT_EPOCH[0]
             for m in self.modules():                  # assign=True loads replace Parameter objects: drop the tensor list then
