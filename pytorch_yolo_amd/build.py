@@ -19,6 +19,7 @@ SOURCES = {
     "runtime.hip": [],
     "conv_igemm.hip": [],
     "conv3x3_halo.hip": [],
+    "conv3x3_t20.hip": [],
     "conv_resunit.hip": [],
     "conv_stem.hip": [],
     "conv_mbconv.hip": [],

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv3x3_halo_kernel(co
 
   // ---- LDS-DMA source offsets (per lane, constant over the whole K loop; chunk / tap go in the scalar offset)
   const int frow = lane / CPR;
-  const int fsw = (CK == 32) ? ((lane >> 4) & 3) : (((lane >> 4) + 4 * (wave & 1)) & 7);   // f(row) of this lane's rows
+  const int fsw = (CK == 32) ? swz32(lane >> 4) : (((lane >> 4) + 4 * (wave & 1)) & 7);   // f(row) of this lane's rows
   const int chunk = (lane & (CPR - 1)) ^ fsw;
   uint32_t h_off[HPT];
 #pragma unroll
@@ -184,13 +184,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv3x3_halo_kernel(co
 #pragma unroll
           for (int i = 0; i < MI; ++i) {
             const int R = wn * TN + i * 32 + r32;
-            const int sw = (CK == 32) ? ((R >> 2) & 3) : ((R >> 1) & 7);
+            const int sw = (CK == 32) ? swz32(R >> 2) : ((R >> 1) & 7);
             wf[i] = *reinterpret_cast<const bf16x8*>(wbuf + R * ROWB + ((g ^ sw) << 4));
           }
 #pragma unroll
           for (int j = 0; j < NI; ++j) {
             const int R = hrow0[j] + toff;
-            const int sw = (CK == 32) ? ((R >> 2) & 3) : ((R >> 1) & 7);
+            const int sw = (CK == 32) ? swz32(R >> 2) : ((R >> 1) & 7);
             xf[j] = *reinterpret_cast<const bf16x8*>(hbuf + R * ROWB + ((g ^ sw) << 4));
           }
 #pragma unroll

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NP)) void conv_igemm_bf16
   // piece p = it*NW + wave covers LDS rows [p*RPP, (p+1)*RPP); lane -> (row in piece, physical chunk slot).
   // swizzle: physical slot = logical chunk ^ f(row);  f = (row>>2)&3 for 64-B rows, (row>>1)&7 for 128-B rows.
   const int frow = lane / CPR;
-  const int fsw = (BK == 32) ? ((lane >> 4) & 3) : (((lane >> 4) + 4 * (lw & 1)) & 7);
+  const int fsw = (BK == 32) ? swz32(lane >> 4) : (((lane >> 4) + 4 * (lw & 1)) & 7);
   const int chunk = (lane & (CPR - 1)) ^ fsw;          // logical 8-channel chunk this lane fetches
   const int ntaps = d.ksize * d.ksize;
   int px_base[PIT], px_hi0[PIT], px_wi0[PIT];          // generic path
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NP)) void conv_igemm_bf16
       // the second K half flips bit 6) plus a compile-time offset that goes into the ds_read immediate.
       const int c16 = lane & 15, q = lane >> 4;
       const int rw0 = wn * TN + c16, rx0 = wm * TM + c16;
-      const int sww = (BK == 32) ? ((rw0 >> 2) & 3) : ((rw0 >> 1) & 7), swx = (BK == 32) ? ((rx0 >> 2) & 3) : ((rx0 >> 1) & 7);
+      const int sww = (BK == 32) ? swz32(rw0 >> 2) : ((rw0 >> 1) & 7), swx = (BK == 32) ? swz32(rx0 >> 2) : ((rx0 >> 1) & 7);
       const int wo = rw0 * ROWB + ((q ^ sww) << 4), xo = rx0 * ROWB + ((q ^ swx) << 4);
 #pragma unroll
       for (int kk = 0; kk < BK / 32; ++kk) {
@@ -346,13 +346,13 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NP)) void conv_igemm_bf16
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
           const int R = wn * TN + i * 32 + r32;
-          const int sw = (BK == 32) ? ((R >> 2) & 3) : ((R >> 1) & 7);
+          const int sw = (BK == 32) ? swz32(R >> 2) : ((R >> 1) & 7);
           wf[i] = *reinterpret_cast<const bf16x8*>(wbuf + R * ROWB + ((g ^ sw) << 4));
         }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           const int R = wm * TM + j * 32 + r32;
-          const int sw = (BK == 32) ? ((R >> 2) & 3) : ((R >> 1) & 7);
+          const int sw = (BK == 32) ? swz32(R >> 2) : ((R >> 1) & 7);
           xf[j] = *reinterpret_cast<const bf16x8*>(xbuf + R * ROWB + ((g ^ sw) << 4));
         }
 #pragma unroll
@@ -706,6 +706,12 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
   const bool epi = d.out_dtype == YOLO_DT_BF16 && d.cout % 32 == 0 && d.out_c_offset % 8 == 0 && d.out_c_total % 8 == 0 &&
                    (!res || (d.res_c_offset % 8 == 0 && d.res_c_total % 8 == 0)) &&
                    (!y_aux || (d.aux_c_offset % 8 == 0 && d.aux_c_total % 8 == 0)) && !(conv_debug_flags & 16);
+  // 3x3/s1 layers whose maps 20x20 tiles cover and fill the chip with (conv3x3_t20.hip).  YOLO_CONV_PP bit 16: every layer the
+  // kernel can compute, bit 32: ... with 256 couts per workgroup where cout allows, bit 64: never.
+  if (epi && conv_variant_override < 0 && !(conv_pp_mask & 64) && a.splits <= 1) {
+    const int rc = launch_t20_3x3(a, (conv_pp_mask & 16 ? 1 : 0) | (conv_pp_mask & 32 ? 3 : 0), s);
+    if (rc != 1) return rc;
+  }
   if (epi && !(conv_debug_flags & 32) && conv_variant_override < 0 && !(conv_pp_mask & 8)) {   // large 3x3/s1 maps: halo-staged kernel
     a.n_tiles = 0;
     const int rc = launch_halo3x3(a, s);

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(const ConvArgs a) {
 
   // ---- LDS-DMA source offsets: piece p = it * 8 + wave covers LDS rows [16 p, 16 p + 16); lane -> (row, physical chunk)
   const int frow = lane >> 2;
-  const int chunk = (lane & 3) ^ ((lane >> 4) & 3);    // logical 8-channel chunk behind this lane's physical slot
+  const int chunk = (lane & 3) ^ swz32(lane >> 4);    // logical 8-channel chunk behind this lane's physical slot
   const int hw_out = d.ho * d.wo;
   int px_base[PIT];
   uint32_t px_mask[PIT];                               // bit t: tap t of this pixel lies inside the image
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(512) void conv_pp_kernel(const ConvArgs a) {
 
   // fragment addresses: lane = (row c16 of a 16-row block, 8-channel chunk q); rows 16 apart share their swizzle term
   const int c16 = lane & 15, q = lane >> 4;
-  const int frag = ((q ^ ((c16 >> 2) & 3)) << 4) + c16 * ROWB;
+  const int frag = ((q ^ swz32(c16 >> 2)) << 4) + c16 * ROWB;
   const int w_frag = (wn * TN) * ROWB + frag;
   const int x_frag = BN * ROWB + (wm * TM) * ROWB + frag;
 
