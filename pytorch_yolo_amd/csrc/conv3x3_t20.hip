@@ -123,8 +123,8 @@ __global__ __launch_bounds__(64 * (CT / 64) * NWM) void conv3x3_t20_kernel(const
   // are written as asm with the accumulator tied to itself: given the builtin, hipcc renames every accumulator per MFMA and
   // shuffles tiles between the two files (v_accvgpr_*) and scratch inside the loop.  The asm statements are volatile, i.e. issued
   // in program order; every tile sees one MFMA per K step, so no MFMA reads the D of one still in flight.
-  constexpr bool ASM_MFMA = NWM == 1;
-  constexpr int NACC_A = ASM_MFMA ? 16 : 0;
+  constexpr bool ASM_MFMA = true;
+  constexpr int NACC_A = NWM == 1 ? 16 : 0;
   f32x4 acc[4][NMAIN - NACC_A], acca[4][NACC_A ? NACC_A : 1], accl[NL ? NL : 1];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -142,70 +142,95 @@ __global__ __launch_bounds__(64 * (CT / 64) * NWM) void conv3x3_t20_kernel(const
   };
 
   const int nch = d.cin / 32;
-  // ---- prologue: halo of chunk 0, weights of steps 0 and 1
+  auto mfma = [&](auto ic, auto jc, const bf16x8& wa, const bf16x8& xb) {
+    constexpr int i = decltype(ic)::value, jj = decltype(jc)::value;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (jj < NACC_A) {
+      f32x4& t = acca[i][jj];
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(t) : "v"(wa), "v"(xb));
+    } else {
+      f32x4& t = acc[i][jj - NACC_A];
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(t) : "v"(wa), "v"(xb));
+    }
+#endif
+  };
+  // fragment reads of filter tap `tap` (compile-time after unrolling) against the halo bases am / bm / lm
+  auto xread = [&](int jj, int tap, uint32_t am, uint32_t bm) -> bf16x8 {
+    const int toff = ((tap / 3) * kHW2 + tap % 3) * 64;
+    if (jj < NFULL) return ldsr(am, ((4 * (jj / 5)) * kHW2 + 4 * (jj % 5)) * 64 + toff);
+    return ldsr(bm, (16 * kHW2 + 4 * (jj - NFULL)) * 64 + toff);
+  };
+
+  // ---- prologue: halo of chunk 0, weights of steps 0 and 1; then the fragments the first step starts with
 #pragma unroll
   for (int it = 0; it < HPT; ++it) issue_halo(0, 0, it);
   issue_w(0, 0, 0);
   issue_w(1, 0, 1);
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  bf16x8 wf[4], xf[3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) wf[i] = ldsr(W, i * 1024);
+  xf[0] = xread(0, 0, A[0], B[0]);
+  xf[1] = xread(1, 0, A[0], B[0]);
 
+  // Step s = (chunk c, tap): the step's weight fragments and its first two pixel fragments are already in registers (fetched in
+  // the tail of step s-1, from a ring slot / halo buffer made visible by the barrier before it), so the MFMA stream starts right
+  // behind the barrier:
+  //   issue LDS-DMA: weights of step s+2 (ring slot (s+2) % 3, last read in the tail of step s-2), a piece of the next chunk's halo
+  //   patches 0 .. N-3: 4 MFMAs each, the pixel fragment of patch jj+2 fetched meanwhile (three fragment registers in rotation)
+  //   patches N-2, N-1 by cout fragment i: 2 MFMAs, then weight fragment i of step s+1 into the same registers; pixel fragments
+  //   0, 1 of step s+1 around them
+  //   s_waitcnt vmcnt(0); s_barrier: the DMA issued above has landed (step s+1's tail reads it)
   for (int c = 0; c < nch; ++c) {
     const bool next_chunk = c + 1 < nch;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int slot = tap % 3;
-      wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();                 // steps s, s+1 have landed; every wave is done with step s-1
+    static_for<9>([&](auto tc) {
+      constexpr int tap = decltype(tc)::value;
+      constexpr int slot_n = (tap + 1) % 3, tap_n = (tap + 1) % 9;
+      constexpr int par = (tap / 3) & 1, par_n = (tap_n / 3) & 1;
+      constexpr int r = (tap * NMAIN) % 3;          // rotation of the three pixel-fragment registers in this step
       {
-        const int t2 = (tap + 2) % 9, c2 = c + (tap + 2) / 9;
+        constexpr int t2 = (tap + 2) % 9;
+        const int c2 = c + (tap + 2) / 9;
         if (c2 < nch) issue_w((tap + 2) % 3, c2, t2);
         if (tap < HPT && next_chunk) issue_halo((c + 1) & 1, c + 1, tap);
       }
-      const int dh = tap / 3, dw = tap % 3;
-      const int par = dh & 1;
-      const int toff = (dh * kHW2 + dw) * 64;
-      bf16x8 wf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) wf[i] = ldsr(W, slot * WBUF_B + i * 1024);
-      // shared patch (4, 4)
-      if constexpr (NL > 0) {
-        const bf16x8 xl = ldsr(L[par], (16 * kHW2 + 16) * 64 + toff);
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-          const bf16x8 wl = ldsr(WL, slot * WBUF_B + i * 1024);
-          accl[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xl, accl[i], 0, 0, 0);
-        }
-      }
       const uint32_t am = A[par], bm = B[par];
-      bf16x8 xf[3];
-      auto xread = [&](int jj) -> bf16x8 {
-        if (jj < NFULL) return ldsr(am, ((4 * (jj / 5)) * kHW2 + 4 * (jj % 5)) * 64 + toff);
-        return ldsr(bm, (16 * kHW2 + 4 * (jj - NFULL)) * 64 + toff);
-      };
-      xf[0] = xread(0);
-      xf[1] = xread(1);
-      static_for<NMAIN>([&](auto jc) {
+      // the next step's halo bases: the other buffer after tap 8
+      const uint32_t flip = tap == 8 ? (uint32_t)kHaloB : 0u;
+      const uint32_t am_n = A[par_n] ^ flip, bm_n = B[par_n] ^ flip;
+      bf16x8 xl, wl[NL ? NL : 1];
+      if constexpr (NL > 0) {                       // shared patch (4, 4): multiplied behind patch 1
+        xl = ldsr(L[par], (16 * kHW2 + 16) * 64 + ((tap / 3) * kHW2 + tap % 3) * 64);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) wl[i] = ldsr(WL, (tap % 3) * WBUF_B + i * 1024);
+      }
+      static_for<NMAIN - 2>([&](auto jc) {
         constexpr int jj = decltype(jc)::value;
-        if constexpr (jj + 2 < NMAIN) xf[(jj + 2) % 3] = xread(jj + 2);
-        static_for<4>([&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          if constexpr (!ASM_MFMA) {
-            acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[jj % 3], acc[i][jj], 0, 0, 0);
-          } else {
+        xf[(jj + 2 + r) % 3] = xread(jj + 2, tap, am, bm);
+        static_for<4>([&](auto ic) { mfma(ic, jc, wf[decltype(ic)::value], xf[(jj + r) % 3]); });
+        if constexpr (NL > 0 && jj == 1) {
 #if defined(__HIP_DEVICE_COMPILE__)
-            const bf16x8& wa = wf[i];                    // (bound outside the asm: operands alone do not capture in a lambda)
-            const bf16x8& xb = xf[jj % 3];
-            if constexpr (jj < NACC_A) {
-              f32x4& t = acca[i][jj];
-              asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(t) : "v"(wa), "v"(xb));
-            } else {
-              f32x4& t = acc[i][jj - NACC_A];
-              asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(t) : "v"(wa), "v"(xb));
-            }
-#endif
+#pragma unroll
+          for (int i = 0; i < NL; ++i) {
+            f32x4& t = accl[i];                       // (bound outside the asm: operands alone do not capture in a lambda)
+            const bf16x8 &wa = wl[i], &xb = xl;
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(t) : "v"(wa), "v"(xb));
           }
-        });
+#endif
+        }
       });
-    }
+      xf[(NMAIN + r) % 3] = xread(0, tap_n, am_n, bm_n);
+      static_for<4>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        mfma(ic, std::integral_constant<int, NMAIN - 2>{}, wf[i], xf[(NMAIN - 2 + r) % 3]);
+        mfma(ic, std::integral_constant<int, NMAIN - 1>{}, wf[i], xf[(NMAIN - 1 + r) % 3]);
+        wf[i] = ldsr(W, slot_n * WBUF_B + i * 1024);
+      });
+      xf[(NMAIN + 1 + r) % 3] = xread(1, tap_n, am_n, bm_n);
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+    });
     // the other halo buffer (every base is < 32 KiB: the XOR toggles bit 15)
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
@@ -237,8 +262,12 @@ __global__ __launch_bounds__(64 * (CT / 64) * NWM) void conv3x3_t20_kernel(const
     return v;
   };
   // Global accesses of the coalesced phase go through buffer descriptors: address = per-lane byte offset (row of the pass,
-  // 8-cout chunk) + a scalar offset per patch, and a lane whose pixel lies outside the image gets an out-of-range offset
+  // 8-cout chunk) + a wave-uniform offset per patch, and a lane whose pixel lies outside the image gets an out-of-range offset
   // (the store is dropped, the load returns 0) - no 64-bit address arithmetic and no branches per pass.
+  // The patch offset is ADDED INTO THE VGPR offset, not passed in the instruction's SGPR soffset field: hipcc pads the
+  // "VALU overwrites the data registers of a > 64-bit store" hazard only for buffer stores without a register soffset, and with
+  // one it placed a v_or_b32 of a data register right behind buffer_store_dwordx4 - on gfx950 the store then wrote the new
+  // value in its second dword for some lanes (a few wrong output pairs per launch, lanes 12-15 / 28-31).
   const uint32_t y_pitch = (uint32_t)d.out_c_total * 2u, r_pitch = (uint32_t)d.res_c_total * 2u, x_pitch = (uint32_t)d.aux_c_total * 2u;
   const uint32_t npix = (uint32_t)d.n * d.h * d.w;
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, npix * y_pitch, 0x00020000);
@@ -246,16 +275,19 @@ __global__ __launch_bounds__(64 * (CT / 64) * NWM) void conv3x3_t20_kernel(const
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.aux, 0, a.aux ? npix * x_pitch : 0u, 0x00020000);
   const bool cout_ok = cbase < d.cout;              // cout % 64 == 0 (launcher): a wave's group is all-or-nothing
   // pass p of a patch pair covers patch pixels (p & 1) * 8 + crow: (dy, dx) = ((p & 1) * 2 + (crow >> 2), crow & 3)
-  uint32_t lpix[2];                                 // pixel index of this lane's pixel in patch (0, 0), halves 0 / 1
+  uint32_t yo[2], ro[2], ao[2];                     // byte offsets of this lane's pixel of patch (0, 0) in y / residual / pre-add copy
   int ylim[2];                                      // patch row pr holds the pixel iff 4 * pr < ylim[half]
+  const uint32_t ccol = (uint32_t)(cbase + cchunk * 8) * 2u;
 #pragma unroll
   for (int hf = 0; hf < 2; ++hf) {
     const int dyh = hf * 2 + (crow >> 2);
-    lpix[hf] = (uint32_t)((b * d.h + y0 + dyh) * d.w + x0 + (crow & 3));
+    const uint32_t lpix = (uint32_t)((b * d.h + y0 + dyh) * d.w + x0 + (crow & 3));
+    yo[hf] = lpix * y_pitch + (uint32_t)d.out_c_offset * 2u + ccol;
+    ro[hf] = lpix * r_pitch + (uint32_t)d.res_c_offset * 2u + ccol;
+    ao[hf] = lpix * x_pitch + (uint32_t)d.aux_c_offset * 2u + ccol;
     ylim[hf] = cout_ok ? d.h - y0 - dyh : 0;
   }
   const int xlim = d.w - x0 - (crow & 3);           // patch column pc holds the pixel iff 4 * pc < xlim
-  const uint32_t ccol = (uint32_t)(cbase + cchunk * 8) * 2u;
   auto patch_of = [&](int jj, int& pr, int& pc) {
     if (jj < NFULL) {
       pr = RPG * pg + jj / 5;
@@ -265,8 +297,27 @@ __global__ __launch_bounds__(64 * (CT / 64) * NWM) void conv3x3_t20_kernel(const
       pc = RPG * pg + (jj - NFULL);
     }
   };
-  static_for<(NMAIN + 1) / 2>([&](auto jpc) {
-    constexpr int jp = 2 * decltype(jpc)::value;
+  // byte offset of pass `pass` of pair jp (base = yo / ro / ao): out of range when the pixel lies outside the image
+  auto voff = [&](const uint32_t (&base)[2], uint32_t pitch, int jp, int pass) -> uint32_t {
+    int pr, pc;
+    patch_of(jp + (pass >> 1), pr, pc);
+    const int hf = pass & 1;
+    const bool ok = 4 * pr < ylim[hf] && 4 * pc < xlim;
+    return ok ? base[hf] + (uint32_t)(4 * pr * d.w + 4 * pc) * pitch : kOobOffset;
+  };
+  // The residual of pair p + 1 is fetched while pair p is staged and stored: with one or two waves per SIMD nothing else hides
+  // the latency of a load that sits between the LDS read and the store of the same pass.
+  constexpr int NPAIR = (NMAIN + 1) / 2;
+  u32x4 rv[2][4];
+  auto fetch_res = [&](auto jpc) {
+    constexpr int pi = decltype(jpc)::value, jp = 2 * pi;
+#pragma unroll
+    for (int pass = 0; pass < (jp + 1 < NMAIN ? 4 : 2); ++pass)
+      rv[pi & 1][pass] = __builtin_amdgcn_raw_buffer_load_b128(rr, voff(ro, r_pitch, jp, pass), 0, 0);
+  };
+  if (a.res) fetch_res(std::integral_constant<int, 0>{});
+  static_for<NPAIR>([&](auto jpc) {
+    constexpr int pi = decltype(jpc)::value, jp = 2 * pi;
     static_for<(jp + 1 < NMAIN ? 2 : 1)>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
       static_for<4>([&](auto ic) {
@@ -277,15 +328,13 @@ __global__ __launch_bounds__(64 * (CT / 64) * NWM) void conv3x3_t20_kernel(const
         *reinterpret_cast<f32x4*>(stg + (u * 16 + c16) * kEpiPitch2 + (i * 16 + q * 4) * 4) = act4(av + bv[i]);
       });
     });
+    if constexpr (pi + 1 < NPAIR) {
+      if (a.res) fetch_res(std::integral_constant<int, pi + 1>{});
+    }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int pass = 0; pass < (jp + 1 < NMAIN ? 4 : 2); ++pass) {
       const int row = pass * 8 + crow;              // 0..31: patch jp + (row >> 4), patch pixel row & 15
-      int pr, pc;
-      patch_of(jp + (pass >> 1), pr, pc);
-      const int hf = pass & 1;
-      const bool ok = 4 * pr < ylim[hf] && 4 * pc < xlim;
-      const uint32_t ppix = (uint32_t)(4 * pr * d.w + 4 * pc);      // wave-uniform
       const f32x4 lo = *reinterpret_cast<const f32x4*>(stg + row * kEpiPitch2 + cchunk * 32);
       const f32x4 hi = *reinterpret_cast<const f32x4*>(stg + row * kEpiPitch2 + cchunk * 32 + 16);
       float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -293,20 +342,17 @@ __global__ __launch_bounds__(64 * (CT / 64) * NWM) void conv3x3_t20_kernel(const
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-        const uint32_t vo = ok ? lpix[hf] * x_pitch + (uint32_t)d.aux_c_offset * 2u + ccol : kOobOffset;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ra, vo, ppix * x_pitch, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ra, voff(ao, x_pitch, jp, pass), 0, 0);
       }
       if (a.res) {
-        const uint32_t vo = ok ? lpix[hf] * r_pitch + (uint32_t)d.res_c_offset * 2u + ccol : kOobOffset;
-        const bf16x8 rv = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rr, vo, ppix * r_pitch, 0));
+        const bf16x8 r8 = __builtin_bit_cast(bf16x8, rv[pi & 1][pass]);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+        for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
       }
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-      const uint32_t vo = ok ? lpix[hf] * y_pitch + (uint32_t)d.out_c_offset * 2u + ccol : kOobOffset;
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, vo, ppix * y_pitch, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, voff(yo, y_pitch, jp, pass), 0, 0);
     }
     __builtin_amdgcn_wave_barrier();
   });
