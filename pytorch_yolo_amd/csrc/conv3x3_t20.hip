@@ -242,6 +242,7 @@ __global__ __launch_bounds__(64 * (CT / 64) * NWM) void conv3x3_t20_kernel(const
 #if defined(__HIP_DEVICE_COMPILE__)
   if constexpr (ASM_MFMA) asm volatile("s_nop 15\n\ts_nop 15");   // the last asm MFMAs' D registers: 12 wait states before any other reader
 #endif
+  if (a.debug & 8) return;                          // timing-only ablation (YOLO_CONV_DEBUG bit 8): no epilogue, y is not written
   __syncthreads();                                  // every wave is done with the ring: the epilogue slabs reuse it
 
   // ---- epilogue
@@ -389,6 +390,230 @@ __global__ __launch_bounds__(64 * (CT / 64) * NWM) void conv3x3_t20_kernel(const
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Second form: 4 waves, 400 pixels x 128 couts per workgroup, TWO workgroups per CU (72 KB of LDS, 256 registers).
+//   * a wave owns 32 couts (two fragments) x all 25 patches: its weight fragments are nobody else's, so they never touch LDS -
+//     each lane fetches its 16 bytes of W[cout row][k] straight into registers (buffer_load_dwordx4, three register sets in
+//     rotation, two steps ahead).  No weight ring, no LDS-DMA for weights, and the only barrier left in the main loop is the one
+//     that hands over a halo buffer: one per 9 steps.
+//   * two resident workgroups drift apart, so one's epilogue (HBM-bound: 100 KB written + 100 KB of residual read) runs under the
+//     other's MFMA stream; with two sub-batch streams the second workgroup of a CU can come from the other stream's launch.
+//   * epilogue: the four waves stage a patch pair as [32 pixels][128 couts] fp32 in LDS (two buffers in turn, one barrier per
+//     pair) and store whole 256-byte pixel rows.
+constexpr int kV2Hofs = 8 * 256 * 4;                 // per-thread halo source offsets (8 pieces per wave): kept in LDS, not in registers
+constexpr int kV2Pitch = 528;                        // fp32 staging row: 128 couts + 16 B
+constexpr int kV2Lds = 2 * kHaloB + kV2Hofs;
+static_assert(2 * 32 * kV2Pitch <= 2 * kHaloB, "epilogue buffers reuse the halo region");
+
+__global__ __launch_bounds__(256, 2) void conv3x3_t20v2_kernel(const ConvArgs a) {
+  constexpr int CT = 128, NW = 4, NP = 25, HPT = 8;
+  __shared__ __attribute__((aligned(16))) char smem[kV2Lds];
+  uint32_t* const hofs = reinterpret_cast<uint32_t*>(smem + 2 * kHaloB);
+
+  YOLO_BLOCK_STAMP(a);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const YoloConvDesc& d = a.d;
+  const int tiles_x = (d.w + kT20 - 1) / kT20, tiles_y = (d.h + kT20 - 1) / kT20;
+  int b, y0, x0, n0;
+  {
+    int swz = xcd_swizzle(blockIdx.x, gridDim.x);
+    n0 = (swz % a.n_tiles) * CT;
+    swz /= a.n_tiles;
+    x0 = (swz % tiles_x) * kT20;
+    swz /= tiles_x;
+    y0 = (swz % tiles_y) * kT20;
+    b = swz / tiles_y;
+  }
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+
+  // ---- halo pieces of this wave: piece (it * 4 + wave) = LDS rows [16 piece, +16); lane -> (row lane >> 2, physical slot lane & 3)
+#pragma unroll
+  for (int it = 0; it < HPT; ++it) {
+    const int hp = (it * NW + wave) * 16 + (lane >> 2);
+    const int hy = hp / kHW2, hx = hp - hy * kHW2;
+    const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+    const int chunk = (lane & 3) ^ ((hy & 1) << 1);
+    const bool ok = hp < kHP && (unsigned)yy < (unsigned)d.h && (unsigned)xx < (unsigned)d.w;
+    const uint32_t ho = ok ? (uint32_t)((((b * d.h + yy) * d.w + xx) * d.in_c_total + d.in_c_offset + chunk * 8) * 2) : kOobOffset;
+    hofs[it * 256 + tid] = ho;
+    lds_dma16s(rx, smem + (it * NW + wave) * 1024, ho, 0u);          // chunk 0 -> halo buffer 0
+  }
+  auto issue_halo = [&](int hb, int c, int it) {
+    lds_dma16s(rx, smem + hb * kHaloB + (it * NW + wave) * 1024, hofs[it * 256 + tid], (uint32_t)c * 64u);
+  };
+
+  // ---- fragment addressing
+  const int c16 = lane & 15, q = lane >> 4;
+  const int dy = c16 >> 2, dx = c16 & 3;
+  uint32_t A[2];                                       // halo bases by parity of (dy + dh), see the first form
+#pragma unroll
+  for (int par = 0; par < 2; ++par) A[par] = (uint32_t)((dy * kHW2 + dx) * 64 + ((q ^ (((dy + par) & 1) << 1)) << 4));
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(A[0]), "+v"(A[1]));
+#endif
+  const uint32_t wv = (uint32_t)(((n0 + wave * 32 + c16) * d.kpad + q * 8) * 2);   // this lane's 16 bytes of fragment 0, k = 0
+  const uint32_t wfrag = (uint32_t)(16 * d.kpad * 2);                             // fragment 1: 16 cout rows further
+  auto wload = [&](int c, int tap, int i) -> bf16x8 {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, wv, (uint32_t)((tap * d.cin + c * 32) * 2) + i * wfrag, 0));
+  };
+  auto ldsr = [&](uint32_t off, int imm) -> bf16x8 {
+    const char* const p = smem + off;
+    return *reinterpret_cast<const bf16x8*>(p + imm);
+  };
+  auto xread = [&](int jj, int tap, uint32_t am) -> bf16x8 {
+    return ldsr(am, ((4 * (jj / 5)) * kHW2 + 4 * (jj % 5)) * 64 + ((tap / 3) * kHW2 + tap % 3) * 64);
+  };
+
+  f32x4 acc[2][NP];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mfma = [&](auto ic, auto jc, const bf16x8& wa, const bf16x8& xb) {
+    constexpr int i = decltype(ic)::value, jj = decltype(jc)::value;
+    f32x4& t = acc[i][jj];
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(t) : "v"(wa), "v"(xb));
+#endif
+  };
+
+  const int nch = d.cin / 32;
+  bf16x8 wf[3][2], xf[3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    wf[0][i] = wload(0, 0, i);
+    wf[1][i] = wload(0, 1, i);
+  }
+  wait_vmcnt<4>();                                     // the halo DMAs (issued before the four weight loads) have landed
+  __builtin_amdgcn_s_barrier();
+
+  for (int c = 0; c < nch; ++c) {
+    static_for<9>([&](auto tc) {
+      constexpr int tap = decltype(tc)::value;
+      constexpr int par = (tap / 3) & 1, par_n = (((tap + 1) % 9) / 3) & 1;
+      // next chunk's halo (the last chunk fetches a dummy one: the vmcnt arithmetic stays uniform), then the weights of step + 2
+      if constexpr (tap < HPT) issue_halo((c + 1) & 1, c + 1, tap);
+      {
+        constexpr int t2 = (tap + 2) % 9;
+        const int c2 = c + (tap + 2) / 9;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wf[(tap + 2) % 3][i] = wload(c2, t2, i);
+      }
+      const uint32_t am = A[par], am_n = A[par_n];
+      if constexpr (tap == 0) {                        // a new halo buffer: nothing of it could be fetched before the barrier
+        xf[0] = xread(0, 0, am);
+        xf[1] = xread(1, 0, am);
+      }
+      static_for<NP>([&](auto jc) {
+        constexpr int jj = decltype(jc)::value;
+        if constexpr (jj + 2 < NP) xf[(jj + 2 + tap) % 3] = xread(jj + 2, tap, am);
+        else if constexpr (tap < 8) xf[(jj + 2 + tap) % 3] = xread(jj + 2 - NP, tap + 1, am_n);   // the next step's first two
+        static_for<2>([&](auto ic) { mfma(ic, jc, wf[tap % 3][decltype(ic)::value], xf[(jj + tap) % 3]); });
+      });
+      if constexpr (tap == 8) {
+        wait_vmcnt<2>();                               // everything but the two youngest weight loads: the next halo has landed
+        __builtin_amdgcn_s_barrier();
+      }
+    });
+    A[0] ^= (uint32_t)kHaloB;
+    A[1] ^= (uint32_t)kHaloB;
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_nop 15\n\ts_nop 15");              // the last asm MFMAs' D registers: 12 wait states before any other reader
+#endif
+  if (a.debug & 8) return;
+
+  // ---- epilogue (the final barrier of the loop has passed: the halo buffers are free; the weight prefetches of the two
+  // steps beyond the end land in registers nobody reads)
+  const int lrow = lane >> 4, cch = lane & 15;          // coalesced phase: 16 lanes per pixel row, 8 couts each
+  f32x4 bv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) bv[i] = *reinterpret_cast<const f32x4*>(a.bias + n0 + wave * 32 + i * 16 + q * 4);
+  const bool floor0 = d.act == YOLO_ACT_RELU || d.act == YOLO_ACT_RELU6;
+  const float slope = d.act == YOLO_ACT_LEAKY01 ? 0.1f : 1.f;
+  const float hi_clamp = d.act == YOLO_ACT_RELU6 ? 6.f : __builtin_inff();
+  auto act4 = [&](f32x4 v) -> f32x4 {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], floor0 ? 0.f : slope * v[e]), hi_clamp);
+    return v;
+  };
+  const uint32_t y_pitch = (uint32_t)d.out_c_total * 2u, r_pitch = (uint32_t)d.res_c_total * 2u, x_pitch = (uint32_t)d.aux_c_total * 2u;
+  const uint32_t npix = (uint32_t)d.n * d.h * d.w;
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, npix * y_pitch, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, a.res ? npix * r_pitch : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.aux, 0, a.aux ? npix * x_pitch : 0u, 0x00020000);
+  // pass u of a pair covers patch jp + u; this lane's pixel of a patch is (dy, dx) = (wave, lrow)
+  const uint32_t lpix = (uint32_t)((b * d.h + y0 + wave) * d.w + x0 + lrow);
+  const uint32_t ccol = (uint32_t)(n0 + cch * 8) * 2u;
+  const uint32_t yo = lpix * y_pitch + (uint32_t)d.out_c_offset * 2u + ccol;
+  const uint32_t ro = lpix * r_pitch + (uint32_t)d.res_c_offset * 2u + ccol;
+  const uint32_t ao = lpix * x_pitch + (uint32_t)d.aux_c_offset * 2u + ccol;
+  const int ylim = d.h - y0 - wave, xlim = d.w - x0 - lrow;       // patch (pr, pc) holds this lane's pixel iff 4 pr < ylim && 4 pc < xlim
+  // (no SGPR soffset on the 16-byte stores: see the first form's epilogue)
+  auto voff = [&](uint32_t base, uint32_t pitch, int jj) -> uint32_t {
+    const int pr = jj / 5, pc = jj % 5;
+    const bool ok = 4 * pr < ylim && 4 * pc < xlim;
+    return ok ? base + (uint32_t)(4 * pr * d.w + 4 * pc) * pitch : kOobOffset;
+  };
+  constexpr int NPAIR = (NP + 1) / 2;
+  u32x4 rv[2][2];
+  auto fetch_res = [&](auto pc_) {
+    constexpr int pi = decltype(pc_)::value, jp = 2 * pi;
+#pragma unroll
+    for (int u = 0; u < (jp + 1 < NP ? 2 : 1); ++u) rv[pi & 1][u] = __builtin_amdgcn_raw_buffer_load_b128(rr, voff(ro, r_pitch, jp + u), 0, 0);
+  };
+  if (a.res) fetch_res(std::integral_constant<int, 0>{});
+  static_for<NPAIR>([&](auto pc_) {
+    constexpr int pi = decltype(pc_)::value, jp = 2 * pi;
+    constexpr int NU = jp + 1 < NP ? 2 : 1;
+    char* const slab = smem + (pi & 1) * (32 * kV2Pitch);
+    static_for<NU>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      static_for<2>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        *reinterpret_cast<f32x4*>(slab + (u * 16 + c16) * kV2Pitch + (wave * 32 + i * 16 + q * 4) * 4) = act4(acc[i][jp + u] + bv[i]);
+      });
+    });
+    if constexpr (pi + 1 < NPAIR) {
+      if (a.res) fetch_res(std::integral_constant<int, pi + 1>{});
+    }
+    __syncthreads();                                    // the pair is staged by all four waves (and pair pi - 1 has been read by all)
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int row = u * 16 + wave * 4 + lrow;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + row * kV2Pitch + cch * 32);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + row * kV2Pitch + cch * 32 + 16);
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      if (a.aux) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ra, voff(ao, x_pitch, jp + u), 0, 0);
+      }
+      if (a.res) {
+        const bf16x8 r8 = __builtin_bit_cast(bf16x8, rv[pi & 1][u]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, voff(yo, y_pitch, jp + u), 0, 0);
+    }
+  });
+}
+
+int launch_t20v2(const ConvArgs& a, hipStream_t s) {
+  ConvArgs b = a;
+  b.n_tiles = a.d.cout / 128;
+  const long grid = (long)a.d.n * ((a.d.h + kT20 - 1) / kT20) * ((a.d.w + kT20 - 1) / kT20) * b.n_tiles;
+  if (grid > 0x7fffffffL) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv grid too large");
+  hipLaunchKernelGGL(conv3x3_t20v2_kernel, dim3((unsigned)grid), dim3(256), 0, s, b);
+  return yolo_check_launch("yolo_conv2d_fwd(t20v2)");
+}
+
 template <int CT, int NWM>
 int launch_t20(const ConvArgs& a, hipStream_t s) {
   ConvArgs b = a;
@@ -418,9 +643,13 @@ int yolo_conv::launch_t20_3x3(const ConvArgs& a, int force, hipStream_t s) {
   const long tiles = (long)d.n * ((d.h + kT20 - 1) / kT20) * ((d.w + kT20 - 1) / kT20);
   if (!force) {
     if ((double)d.n * d.h * d.w < 0.9 * 400.0 * tiles) return 1;          // partial tiles idle lanes
-    if (tiles * (d.cout / 128) < 224) return 1;                           // would not fill the 256 CUs
+    // The second form is the shipped one: 400 pixels x 128 couts per workgroup, two workgroups per CU.  It needs enough workgroups
+    // for half the chip (the other sub-batch stream's launch fills the rest): 16 images of the 20x20 maps give 128.
+    if (tiles * (d.cout / 128) < 128) return 1;
+    return launch_t20v2(a, s);
   }
-  // 256 couts per workgroup halve the halo traffic; 128 double the workgroup count
+  if (force & 4) return launch_t20v2(a, s);
+  // first form (kept for A/B runs): 256 couts per workgroup halve the halo traffic; 128 double the workgroup count
   if (d.cout % 256 == 0 && (tiles * (d.cout / 256) >= 224 || (force & 2))) return launch_t20<256, 1>(a, s);
   return launch_t20<128, 4>(a, s);
 }

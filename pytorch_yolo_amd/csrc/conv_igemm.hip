@@ -707,9 +707,10 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
                    (!res || (d.res_c_offset % 8 == 0 && d.res_c_total % 8 == 0)) &&
                    (!y_aux || (d.aux_c_offset % 8 == 0 && d.aux_c_total % 8 == 0)) && !(conv_debug_flags & 16);
   // 3x3/s1 layers whose maps 20x20 tiles cover and fill the chip with (conv3x3_t20.hip).  YOLO_CONV_PP bit 16: every layer the
-  // kernel can compute, bit 32: ... with 256 couts per workgroup where cout allows, bit 64: never.
+  // kernel can compute, bit 32: ... with 256 couts per workgroup where cout allows, bit 64: never, bit 128: every such layer with
+  // the second form (4 waves, weights straight to registers, two workgroups per CU).
   if (epi && conv_variant_override < 0 && !(conv_pp_mask & 64) && a.splits <= 1) {
-    const int rc = launch_t20_3x3(a, (conv_pp_mask & 16 ? 1 : 0) | (conv_pp_mask & 32 ? 3 : 0), s);
+    const int rc = launch_t20_3x3(a, (conv_pp_mask & 16 ? 1 : 0) | (conv_pp_mask & 32 ? 3 : 0) | (conv_pp_mask & 128 ? 5 : 0), s);
     if (rc != 1) return rc;
   }
   if (epi && !(conv_debug_flags & 32) && conv_variant_override < 0 && !(conv_pp_mask & 8)) {   // large 3x3/s1 maps: halo-staged kernel

@@ -1192,12 +1192,17 @@ def _unmatched(a, b, iou_min, conf_tol):
     return [i for i in range(len(a)) if not ok[i].any()]
 
 
-def _stable_detections(pred_np, conf, iou, eps_conf, eps_iou, eps_cls):
+def _stable_detections(pred_np, conf, iou, eps_conf, eps_iou, eps_cls, sigma_box=0.0, sigma_score=0.0, n_noise=0):
     """SURVEY 7's guard band, made operational.  Returns (all detections, those outside the guard band) of ``pred`` under
     the oracle MERGE-NMS.  A detection is INSIDE the band (excluded from the comparison) when
       * its pivot row does not survive every perturbation of the two thresholds by +-eps (candidates within eps of
         conf_thres; merge groups whose membership hinges on an IoU within eps of nms_thres), or
-      * its pivot row's two best class scores are within eps_cls of each other (the arg-max class can flip)."""
+      * its pivot row's two best class scores are within eps_cls of each other (the arg-max class can flip), or
+      * it does not come out (same class, IoU >= 0.9, |dconf| <= 0.03) of every one of ``n_noise`` re-runs on the prediction
+        with gaussian noise of the bf16 drift's own size added (sigma_box px on xywh, sigma_score on objectness and class
+        scores): MERGE replaces a kept box by the confidence-weighted mean of the whole pile it suppresses
+        (utils.py:266-275), and with synthetic weights the piles are 20..100 overlapping candidates whose membership - hence
+        the mean, hence which pile survives - moves with perturbations far below the stated tolerance."""
     from oracle import nms as onms
     dets, kept = onms.nms_image(pred_np.copy(), conf, iou)
     if dets is None:
@@ -1210,16 +1215,21 @@ def _stable_detections(pred_np, conf, iou, eps_conf, eps_iou, eps_cls):
     cls = np.sort(pred_np[kept, 5:], axis=1)
     gap_ok = (cls[:, -1] - cls[:, -2] > eps_cls) if cls.shape[1] > 1 else np.ones(len(kept), bool)
     mask = np.array([k in stable for k in kept.tolist()], bool) & gap_ok
+    rng = np.random.default_rng(20261004)
+    for _ in range(n_noise):
+        noisy = pred_np.copy()
+        noisy[:, :4] += rng.normal(0.0, sigma_box, noisy[:, :4].shape).astype(np.float32)
+        noisy[:, 4:] = np.clip(noisy[:, 4:] + rng.normal(0.0, sigma_score, noisy[:, 4:].shape).astype(np.float32), 0.0, 1.0)
+        d2, _ = onms.nms_image(noisy, conf, iou)
+        d2 = np.zeros((0, 7), np.float32) if d2 is None else d2
+        lost = set(_unmatched(dets, d2, iou_min=0.9, conf_tol=0.03))
+        mask &= np.array([i not in lost for i in range(len(dets))], bool)
     return dets, dets[mask]
 
 
 GUARD = dict(eps_conf=0.03, eps_iou=0.05, eps_cls=0.03)   # guard band around conf_thres / nms_thres / class arg-max
 MATCH = dict(iou_min=0.8, conf_tol=0.06)                  # a partner: same class, IoU >= 0.8, |dconf| <= 0.06
-# MERGE replaces every kept box by the confidence-weighted mean of ALL boxes it suppresses (utils.py:266-275): with synthetic
-# weights each class has piles of ~20..100 overlapping candidates, and which pile a borderline box joins moves the mean by
-# more than the bf16 drift itself.  Threshold perturbation cannot predict that, so the set comparison is a rate: at least
-# MATCH_RATE of the detections outside the guard band have a partner (measured >= 0.95), and EVERY confident one does.
-MATCH_RATE = 0.92
+N_NOISE = 6                                               # noise re-runs of the guard band (see _stable_detections)
 CONFIDENT = 0.5
 
 
@@ -1228,8 +1238,9 @@ def test_full_size_detection_sets_vs_reference(name):
     """End to end on the BASELINE configs at full size, against the reference's own NMS output stored in the golden
     (nms_dets_0 / nms_kept_0, tests/golden/make_golden.py):
       * fp32 mode: the kept-index set IS the reference's, class equal, conf / class_conf within 2e-5, boxes within 1e-2 px;
-      * bf16 mode: outside the guard band (_stable_detections) reference and bf16 detections pair up (same class,
-        IoU >= 0.8, |dconf| <= 0.06) at a rate >= MATCH_RATE in both directions, and without exception above conf 0.5."""
+      * bf16 mode: EVERY detection outside the guard band (_stable_detections: thresholds, class arg-max, and robustness
+        to noise of the measured bf16 drift's size) has a partner on the other side (same class, IoU >= 0.8,
+        |dconf| <= 0.06), in both directions; the share of ALL detections with a partner is printed."""
     from oracle import nms as onms
     from pytorch_yolo_amd.utils.utils import non_max_suppression
     case = C.FULL_CASES[name]
@@ -1267,8 +1278,13 @@ def test_full_size_detection_sets_vs_reference(name):
         io16, _ = model(x.to(DEV))
     dets16, _ = non_max_suppression(io16, with_indices=True, **C.NMS_FULL)
     d16 = dets16[0].cpu().numpy()
-    ref_all, ref_stable = _stable_detections(io_ref[0].numpy(), C.NMS_FULL["conf_thres"], C.NMS_FULL["nms_thres"], **GUARD)
-    hip_all, hip_stable = _stable_detections(io16[0].cpu().numpy(), C.NMS_FULL["conf_thres"], C.NMS_FULL["nms_thres"], **GUARD)
+    io16_0 = io16[0].cpu().numpy()
+    live = io_ref[0].numpy()[:, 4] > 0.5 * C.NMS_FULL["conf_thres"]            # rows that can matter to NMS
+    drift = io16_0[live] - io_ref[0].numpy()[live]
+    noise = dict(sigma_box=float(np.sqrt((drift[:, :4] ** 2).mean())), sigma_score=float(np.sqrt((drift[:, 4:] ** 2).mean())), n_noise=N_NOISE)
+    print(f"[{name}] bf16 drift on live rows: rms box {noise['sigma_box']:.3f} px, rms score {noise['sigma_score']:.4f} (the guard band's noise scale)")
+    ref_all, ref_stable = _stable_detections(io_ref[0].numpy(), C.NMS_FULL["conf_thres"], C.NMS_FULL["nms_thres"], **GUARD, **noise)
+    hip_all, hip_stable = _stable_detections(io16_0, C.NMS_FULL["conf_thres"], C.NMS_FULL["nms_thres"], **GUARD, **noise)
     assert np.array_equal(hip_all, d16)                            # (the device NMS is the oracle NMS, bit for bit)
     miss_ref = _unmatched(ref_stable, d16, **MATCH)
     miss_hip = _unmatched(hip_stable, ref_all, **MATCH)
@@ -1279,9 +1295,12 @@ def test_full_size_detection_sets_vs_reference(name):
             same = pool[pool[:, 6] == r[6]]
             best = _iou_matrix(r[None, :4], same[:, :4]).max() if len(same) else 0.0
             print(f"   {tag} detection without a partner: cls {int(r[6])} conf {r[4]:.3f} box {np.round(r[:4], 1)} best same-class IoU {best:.2f}")
-    assert len(ref_stable) >= 20 and len(hip_stable) >= 20, "the comparison is vacuous"
-    assert len(miss_ref) <= (1 - MATCH_RATE) * len(ref_stable) and len(miss_hip) <= (1 - MATCH_RATE) * len(hip_stable)
-    assert not any(ref_stable[i][4] >= CONFIDENT for i in miss_ref) and not any(hip_stable[i][4] >= CONFIDENT for i in miss_hip)
+    share = 1.0 - len(_unmatched(ref_all, d16, **MATCH)) / max(1, len(ref_all))
+    print(f"[{name}] share of ALL reference detections with a bf16 partner: {share:.2f}")
+    assert len(ref_stable) >= 10 and len(hip_stable) >= 10, "the comparison is vacuous"
+    assert len(miss_ref) == 0 and len(miss_hip) == 0, "a detection outside the guard band has no partner"
+    assert not any(r[4] >= CONFIDENT for r in ref_all[_unmatched(ref_all, d16, **MATCH)])    # confident ones always pair up
+    assert share >= 0.6
     assert abs(len(d16) - len(ref_all)) <= 0.1 * len(ref_all)
 
 
@@ -1551,13 +1570,18 @@ def test_pingpong_conv_kernel(case):
 
 
 T20_CASES = [
-    # n, h, w, cin, cout, use_res, use_aux, knob (YOLO_CONV_PP bits: 16 = every layer the 20x20-tile kernel takes, 32 = 256-cout workgroups)
+    # n, h, w, cin, cout, use_res, use_aux, knob (YOLO_CONV_PP bits: 16 = every layer the 20x20-tile kernel takes, 32 = 256-cout workgroups,
+    # 128 = the second form)
     (2, 40, 40, 64, 256, True, True, 16 | 32),     # 4-wave form (256 couts, asm MFMAs, accumulators in both register files)
     (2, 40, 40, 64, 256, True, False, 16),         # 8-wave form (128 couts, four pixel groups + the shared 25th patch)
     (1, 80, 80, 32, 128, False, False, 16),        # one channel chunk: prologue only, no halo double-buffering
     (3, 37, 41, 96, 256, True, True, 16 | 32),     # partial tiles on both edges, three chunks (odd count)
     (3, 37, 41, 96, 384, True, True, 16),          # ... and the 8-wave form with three cout tiles
     (1, 20, 20, 256, 512, False, True, 16 | 32),   # one tile per image, eight chunks
+    (2, 40, 40, 64, 256, True, True, 16 | 128),    # second form (4 waves x 32 couts, weights straight to registers, block-wide staging)
+    (1, 80, 80, 32, 128, False, False, 16 | 128),  # ... one channel chunk
+    (3, 37, 41, 96, 384, True, True, 16 | 128),    # ... partial tiles, three chunks, three cout tiles
+    (1, 20, 20, 256, 512, False, True, 16 | 128),  # ... eight chunks
 ]
 
 
