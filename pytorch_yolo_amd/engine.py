@@ -418,11 +418,75 @@ class Plan:
         if mid.buf in self._bufs:
             self._bufs.remove(mid.buf)
 
+    def _live_ranges(self):
+        """[first, last] launch-order index at which each buffer is touched.  A buffer is touched by the producer and by every
+        consumer of each tensor placed in it (views, concat slices, in-place residual outputs and upsample targets share their
+        buffer, so they widen ITS range); None for a buffer some tensor of which has no producer / is a model output."""
+        nodes = self.rec.nodes
+        order = {id(nd): i for i, nd in enumerate(nodes)}
+        rng = {}
+        pinned = set()
+
+        def touch(buf, i):
+            if buf is None:
+                return
+            lo, hi = rng.get(id(buf), (i, i))
+            rng[id(buf)] = (min(lo, i), max(hi, i))
+
+        for nd in nodes:
+            i = order[id(nd)]
+            for s_ in list(nd.srcs) + list(nd.outs):
+                touch(s_.buf, i)
+            for key in ("up_into", "pool_into"):                 # a conv that stores into another node's output buffer
+                if key in nd.attrs:
+                    touch(nd.attrs[key].buf, i)
+            for key in ("fuse_pre", "stem_pre"):                 # fused pairs: the later node's launch reads the earlier node's inputs
+                pre = nd.attrs.get(key)
+                if pre is not None:
+                    for s_ in pre.srcs:
+                        touch(s_.buf, i)
+            if "mb_pre" in nd.attrs:
+                ex, dwn, x = nd.attrs["mb_pre"]
+                touch(x.buf, i)
+            if nd.kind in ("input", "head"):
+                for s_ in list(nd.srcs) + list(nd.outs):
+                    if s_.buf is not None:
+                        pinned.add(id(s_.buf))
+        return rng, pinned
+
     def _alloc(self):
-        for b in self._bufs:
+        """One torch tensor per buffer; buffers of identical shape whose live ranges do not overlap share storage
+        (YOLO_REUSE_BUFFERS=0 turns that off).  Sharing keeps a residual stage's working set - the stream x (in place) and ONE
+        intermediate t instead of one per unit - inside the 256 MB Infinity Cache, and a dead intermediate is overwritten there
+        instead of being written back to HBM.  Only buffers that their producers fill completely take part (a padded
+        buffer relies on its zero fill)."""
+        reuse = os.environ.get("YOLO_REUSE_BUFFERS", "1") == "1" and not self.f32
+        rng, pinned = self._live_ranges() if reuse else ({}, set())
+        filled = {}
+        for nd in self.rec.nodes:
+            for s_ in nd.outs:
+                if s_.buf is not None:
+                    filled[id(s_.buf)] = filled.get(id(s_.buf), 0) + s_.c
+        pool = {}                                                   # shape key -> [(last use, tensor)]
+        self.shared_buffers = 0
+        for b in sorted(self._bufs, key=lambda b_: rng.get(id(b_), (0, 0))[0]):
             dt = torch.float32 if (b.f32 or self.f32) else torch.bfloat16
             ct = K.roundup(b.c_total, 8)
+            exact = ct == b.c_total and filled.get(id(b), 0) == b.c_total
             b.c_total = ct
+            key = (b.n, b.h, b.w, ct, dt)
+            lo, hi = rng.get(id(b), (None, None))
+            if reuse and exact and lo is not None and id(b) not in pinned:
+                free = pool.setdefault(key, [])
+                hit = next((e for e in free if e[0] < lo), None)
+                if hit is not None:
+                    free.remove(hit)
+                    b.tensor = hit[1]
+                    self.shared_buffers += 1
+                else:
+                    b.tensor = torch.zeros((b.n, b.h, b.w, ct), dtype=dt, device=self.device)
+                free.append((hi, b.tensor))
+                continue
             # zero-filled once: padded channels (e.g. 255 -> 256 head rows) are never written
             b.tensor = torch.zeros((b.n, b.h, b.w, ct), dtype=dt, device=self.device)
 
@@ -760,7 +824,7 @@ class Plan:
         return io, ps
 
     def activation_bytes(self) -> int:
-        return sum(b.tensor.numel() * b.tensor.element_size() for b in self._bufs)
+        return sum(t.numel() * t.element_size() for t in {b.tensor.data_ptr(): b.tensor for b in self._bufs}.values())
 
     # -- HIP-graph replay ------------------------------------------------------------------------------
     def run_graph(self, x: torch.Tensor):
