@@ -19,8 +19,8 @@ def load(path, counter):
             continue
         k = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
         k = re.sub(r"yolo_conv::", "", k)
-        k = ("conv kernels (conv_igemm_bf16 incl. head+decode / conv3x3_halo / resunit / stem)"
-             if re.search(r"conv_igemm|conv3x3_halo|conv1_nchw|resunit\w*_kernel|stem_kernel", k) else k.split("(")[0][:60])
+        k = ("conv kernels (conv_igemm_bf16 incl. head+decode / conv3x3_t20 / conv3x3_halo / resunit / stem)"
+             if re.search(r"conv_igemm|conv3x3_halo|conv3x3_t20|conv1_nchw|resunit\w*_kernel|stem_kernel", k) else k.split("(")[0][:60])
         per[k] = per.get(k, 0.0) + float(r["Counter_Value"])
         n[k] += 1
     return per, n
@@ -29,7 +29,7 @@ def load(path, counter):
 def main():
     fetch, nf = load(sys.argv[1], "FETCH_SIZE")
     write, _ = load(sys.argv[2], "WRITE_SIZE")
-    steps = int(sys.argv[3])
+    steps = float(sys.argv[3])   # 32-image steps profiled = stem_kernel launches / 2 (two sub-batch streams)
     print("| kernel | launches/step | FETCH_SIZE raw MB/step | read MB/step (x2, gfx950) | WRITE_SIZE MB/step | HBM MB/step |")
     print("|---|---|---|---|---|---|")
     for k in fetch:
