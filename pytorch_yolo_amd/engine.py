@@ -809,6 +809,40 @@ class Plan:
                 total += (2.0 * d.n * d.h * d.w * d.cin * hid if op.w_pre else 0.0) + 2.0 * d.n * d.ho * d.wo * hid * (9 + d.cout)
         return total
 
+    def algorithmic_bytes(self) -> float:
+        """HBM bytes one pass must move if every tensor that exists in HBM is read once and written once:
+        per launch its input view, its output (x4 for a 2x2-replicated store, fp32 head rows + decoded rows for a fused head),
+        the residual and the pre-add copy, and its weights.  Fused launches count only what crosses the chip boundary."""
+        total = 0.0
+        first = True
+        for i in range(self.n_ops):
+            op = self.op_array[i]
+            d = op.conv
+            m_in, m_out = d.n * d.h * d.w, d.n * d.ho * d.wo
+            if op.kind in (OP_CONV, OP_CONV1_NCHW, OP_CONV1_POOL, OP_CONV_POOL, OP_HEAD_DECODE, OP_CONV_F32):
+                x_b = m_in * (self.rec.c_in * 4 if (first and op.kind in (OP_CONV1_NCHW, OP_CONV1_POOL)) else d.cin * (4 if op.kind == OP_CONV_F32 else 2))
+                first = False
+                pooled = 4 if op.kind in (OP_CONV1_POOL, OP_CONV_POOL) else 1       # only the 2x2-pooled map is written
+                y_b = m_out * d.cout * (4 if d.out_dtype else 2) * (4 if d.upsample2x else 1) / pooled
+                if op.kind == OP_HEAD_DECODE:
+                    y_b = 2.0 * m_out * d.cout * 4                                   # p (raw) + io (decoded), fp32
+                total += x_b + y_b + d.cout * d.ksize * d.ksize * d.cin * 2
+                total += (m_out * d.cout * 2 if op.residual else 0) + (m_out * d.cout * 2 if op.y_aux else 0)
+            elif op.kind == OP_STEM:
+                first = False
+                total += m_in * self.rec.c_in * 4 + m_out * 64 * 2
+            elif op.kind == OP_RESUNIT:
+                total += m_in * d.cout * 2 * (3 if op.y_aux else 2)
+            elif op.kind == OP_MBCONV:
+                total += m_in * d.cin * 2 + m_out * d.cout * 2
+            elif op.kind in (OP_MAXPOOL, OP_DWCONV, OP_MAXPOOL_F32):
+                total += (m_in + m_out) * d.cin * (4 if op.kind == OP_MAXPOOL_F32 else 2)
+            elif op.kind == OP_SPP:
+                total += m_in * d.cin * 2 * 4                                        # reads c, writes the three pooled copies
+            elif op.kind == OP_SHUFFLE:
+                total += 2.0 * m_in * d.cin * 2
+        return total
+
     def new_outputs(self):
         n = self.rec.input.n
         no = self.n_class + 5
@@ -932,6 +966,9 @@ class StreamedPlan:
 
     def activation_bytes(self) -> int:
         return sum(p.activation_bytes() for p in self.subs)
+
+    def algorithmic_bytes(self) -> float:
+        return sum(p.algorithmic_bytes() for p in self.subs)
 
 
 StreamedPlan.run_graph = Plan.run_graph

@@ -17,7 +17,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-__all__ = ["synth_state_dict", "synth_images", "key_rng"]
+__all__ = ["synth_state_dict", "synth_images", "key_rng", "calibrate_plain_heads"]
 
 
 def key_rng(seed: int, key: str) -> np.random.Generator:
@@ -160,3 +160,21 @@ def synth_images(bs: int, h: int, w: int, seed: int = 0, channels: int = 3) -> t
         g = np.repeat(np.repeat(g, block, axis=2), block, axis=3)[:, :, :h, :w]
         img += np.float32(amp) * g
     return torch.from_numpy(np.minimum(img, np.float32(0.999999)))
+
+
+def calibrate_plain_heads(model, x, obj_std: float = 2.0) -> float:
+    """Synthetic weights only: rescale the plain (biased 1x1 conv) detection heads so that the objectness logits have the
+    spread HEAD_STATS["plain"] intends (std ``obj_std`` around the bias).  The head gains of synth_state_dict assume unit
+    variance at the head input; an encoder that shrinks its activations (MobileNetV2's linear bottlenecks under this
+    generator) leaves every logit at its bias, sigmoid(-3)^2 < conf_thres, and the NMS leg of a benchmark would be empty.
+    Runs one forward on (a few images of) ``x``; returns the factor applied."""
+    with torch.no_grad():
+        _, p = model(x[: min(4, x.shape[0])])
+    obj = torch.cat([(t[..., 4] - t[..., 4].mean()).flatten() for t in p])
+    f = float(obj_std / max(float(obj.std()), 1e-6))
+    sd = model.state_dict()
+    for k, v in sd.items():
+        if _is_head_key(k) and v.dim() == 4 and ".sequence." not in k:
+            sd[k] = v * f
+    model.load_state_dict(sd)
+    return f
