@@ -27,7 +27,8 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from pytorch_yolo_amd import YOLOv3SPP, YOLOv3Tiny, YOLOv3TinyMobile, YOLOv3TinyShuffle, YOLOv3TinySqueeze          # noqa: E402
+from pytorch_yolo_amd import (YOLOv3SPP, YOLOv3Tiny, YOLOv3TinyEfficient, YOLOv3TinyMobile, YOLOv3TinyShuffle,   # noqa: E402
+                              YOLOv3TinySqueeze)
 from pytorch_yolo_amd.distributed import PipelinedGather                    # noqa: E402
 from pytorch_yolo_amd.utils.synthetic import calibrate_plain_heads, synth_images, synth_state_dict  # noqa: E402
 from pytorch_yolo_amd.utils.utils import nms_capacity, nms_raw               # noqa: E402
@@ -50,6 +51,8 @@ WORKLOADS = {
                     name="YOLOv3-tiny SqueezeNet 1.1 416x416 bs=32/GPU detect()"),
     "shuffle": dict(cls=YOLOv3TinyShuffle, kw=dict(), hw=416, bs=32,
                     name="YOLOv3-tiny ShuffleNetV2 x1.0 416x416 bs=32/GPU detect()"),
+    "efficient": dict(cls=YOLOv3TinyEfficient, kw=dict(), hw=416, bs=32,
+                      name="YOLOv3-tiny EfficientNet-B0 416x416 bs=32/GPU detect()"),
 }
 CONF_THRES, NMS_THRES = 0.1, 0.5
 
@@ -82,7 +85,8 @@ def cpu_baseline(workload: str, seconds_budget: float = 20.0):
     else:
         fwd, cls = {"tiny": (om.tiny_forward, YOLOv3Tiny), "mobile": (om.tiny_mobile_forward, YOLOv3TinyMobile),
                     "squeeze": (om.tiny_squeeze_forward, YOLOv3TinySqueeze),
-                    "shuffle": (om.tiny_shuffle_forward, YOLOv3TinyShuffle)}[workload]
+                    "shuffle": (om.tiny_shuffle_forward, YOLOv3TinyShuffle),
+                    "efficient": (om.tiny_efficient_forward, YOLOv3TinyEfficient)}[workload]
         anchors, hw = om.TINY_ANCHORS, 416
         tmpl = cls().state_dict()
     cores = host_cores()

@@ -34,7 +34,8 @@ typedef void* yolo_stream_t; /* hipStream_t */
 #endif
 
 enum { YOLO_E_ARG = -1, YOLO_E_UNSUPPORTED = -2, YOLO_E_WORKSPACE = -3 };
-enum { YOLO_ACT_NONE = 0, YOLO_ACT_LEAKY01 = 1, YOLO_ACT_RELU6 = 2, YOLO_ACT_RELU = 3 };
+enum { YOLO_ACT_NONE = 0, YOLO_ACT_LEAKY01 = 1, YOLO_ACT_RELU6 = 2, YOLO_ACT_RELU = 3,
+       YOLO_ACT_SWISH = 4 /* x * sigmoid(x): SwissActivation, models/yolov3_tiny_efficient.py:13-19 */ };
 enum { YOLO_DT_BF16 = 0, YOLO_DT_F32 = 1 };
 
 YOLO_API const char* yolo_last_error(void);
@@ -61,7 +62,10 @@ typedef struct YoloConvDesc {
   int32_t n, h, w;                 /* input batch / spatial size                           */
   int32_t cin;                     /* logical input channels, multiple of 8                */
   int32_t in_c_total, in_c_offset; /* input view                                           */
-  int32_t ho, wo;                  /* conv output spatial size (before optional upsample)  */
+  int32_t ho, wo;                  /* conv output spatial size (before optional upsample):
+                                      (h + 2 pad - ksize) / stride + 1, or ONE more - the window of the last row /
+                                      column then hangs over the bottom / right edge by one more zero (TensorFlow
+                                      "same" padding of efficientnet_pytorch's Conv2dSamePadding at stride 2)       */
   int32_t cout;                    /* logical output channels                              */
   int32_t out_c_total, out_c_offset;
   int32_t ksize, stride, pad;      /* square kernel 1 or 3; zero padding                   */
@@ -122,6 +126,24 @@ YOLO_API int yolo_conv3x3_pool_fwd(const void* x, const void* w_packed, const fl
 YOLO_API int yolo_dwconv3x3_fwd(const void* x, const float* w, const float* bias, void* y, int n, int h, int w_,
                        int c, int in_c_total, int in_c_offset, int ho, int wo, int out_c_total,
                        int out_c_offset, int stride, int act, yolo_stream_t s);
+
+/* ---- depthwise k x k conv (k = 3 or 5) + bias + act with an explicit leading pad (rows above / columns left of the image);
+ *      windows that hang over the bottom / right edge read zeros, so TensorFlow "same" padding (efficientnet_pytorch 0.2.0
+ *      Conv2dSamePadding: stride 2 on an even map pads 0 + 1 for k = 3, 1 + 2 for k = 5) is pad = pad_total / 2 with the caller's
+ *      ho x wo = ceil(h / stride) x ceil(w / stride).  EfficientNet-B0's MBConvBlock._depthwise_conv behind
+ *      models/yolov3_tiny_efficient.py:22-45.  w: f32 [k*k][c] tap-major, bias f32 [c]. */
+YOLO_API int yolo_dwconv_fwd(const void* x, const float* w, const float* bias, void* y, int n, int h, int w_, int c,
+                             int in_c_total, int in_c_offset, int ho, int wo, int out_c_total, int out_c_offset, int ksize,
+                             int stride, int pad, int act, yolo_stream_t s);
+
+/* ---- squeeze-and-excitation of an MBConvBlock (efficientnet_pytorch 0.2.0 model.py, used through
+ *      models/yolov3_tiny_efficient.py:47-56): y = x * sigmoid(W2 swish(W1 mean_hw(x) + b1) + b2), per image and channel.
+ *      x, y: bf16 NHWC views of c channels (y may be x); w1: f32 [squeeze][c], b1 f32 [squeeze], w2: f32 [c][squeeze],
+ *      b2 f32 [c]; workspace: yolo_se_workspace_bytes(n, c) bytes (pooled means + scales, fp32). */
+YOLO_API size_t yolo_se_workspace_bytes(int n, int c);
+YOLO_API int yolo_se_fwd(const void* x, void* y, int n, int h, int w, int c, int in_c_total, int in_c_offset, int out_c_total,
+                         int out_c_offset, const float* w1, const float* b1, const float* w2, const float* b2, int squeeze,
+                         void* workspace, size_t ws_bytes, yolo_stream_t s);
 
 /* ---- ShuffleNetV2's channel_shuffle(cat(a, b), groups = 2) (torchvision shufflenetv2, used by
  *  models/yolov3_tiny_shuffle.py:13-47): a and b are bf16 NHWC views holding `half` logical channels each in slots of
@@ -252,11 +274,13 @@ enum { YOLO_OP_CONV = 1, YOLO_OP_MAXPOOL = 2, YOLO_OP_SPP = 3, YOLO_OP_DWCONV = 
        YOLO_OP_RESUNIT = 6, YOLO_OP_STEM = 7, YOLO_OP_HEAD_DECODE = 8, YOLO_OP_CONV1_POOL = 9, YOLO_OP_MBCONV = 10,
        YOLO_OP_CONV_POOL = 11 /* yolo_conv3x3_pool_fwd with pool = 1: x = bf16 NHWC, y = the pooled map */,
        YOLO_OP_SHUFFLE = 12 /* yolo_channel_shuffle2_fwd: x = a, residual = b, conv.cin = c_slot, conv.cout = half, res_* = view of b */,
-       YOLO_OP_CONV_F32 = 13 /* yolo_conv2d_f32_fwd */, YOLO_OP_MAXPOOL_F32 = 14 /* yolo_maxpool_f32_fwd, fields as MAXPOOL */ };
+       YOLO_OP_CONV_F32 = 13 /* yolo_conv2d_f32_fwd */, YOLO_OP_MAXPOOL_F32 = 14 /* yolo_maxpool_f32_fwd, fields as MAXPOOL */,
+       YOLO_OP_SE = 15 /* yolo_se_fwd: x / y views in conv (n, h, w, cin, in_*, out_*), w / bias = W1 / b1, w_pre / bias_pre = W2 / b2,
+                          kpad_pre = squeezed channels, workspace / ws_bytes */ };
 typedef struct YoloOp {
   int32_t kind, _pad;
   const void* x; const void* w; const float* bias; const void* residual; void* y; void* y_aux;
-  YoloConvDesc conv;             /* kind CONV; DWCONV/MAXPOOL/SPP reuse the geometry fields
+  YoloConvDesc conv;             /* kind CONV; DWCONV/MAXPOOL/SPP reuse the geometry fields (DWCONV with ksize 0: the 3x3 / pad 1 form)
                                     (ksize/stride/pad, act, views); MAXPOOL dilation = upsample2x field;
                                     CONV1_NCHW: x = f32 NCHW input, res_c_total = real input channels;
                                     RESUNIT: the unit's 3x3 (w/bias = W2/b2), see yolo_resunit_fwd;

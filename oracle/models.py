@@ -124,6 +124,17 @@ def tiny_mobile_forward(sd, x, anchors=TINY_ANCHORS, n_class=80):
     return tiny_mobile_head_forward(sd, route1, route2, max(x.shape[-2:]), anchors, n_class)
 
 
+def tiny_efficient_forward(sd, x, anchors=TINY_ANCHORS, n_class=80):
+    """YOLOv3TinyEfficient.forward (eval) - yolov3_tiny_efficient.py:114-147 (the tiny-style head, :84-100: widths 128 / 128,
+    the same wiring as yolov3_tiny.py); encoder: oracle/efficientnet.py (parity unpinned, see its header)."""
+    from .efficientnet import efficientnet_routes
+    route1, route2 = efficientnet_routes(sd, x)
+    heads = _tiny_heads(sd, route1, route2)
+    outs = [yolo_decode(h, a, n_class, max(x.shape[-2:])) for h, a in zip(heads, anchors)]
+    io, p = zip(*outs)
+    return torch.cat(io, 1), tuple(p)
+
+
 def tiny_shuffle_forward(sd, x, anchors=TINY_ANCHORS, n_class=80):
     """YOLOv3TinyShuffle.forward (eval) — yolov3_tiny_shuffle.py:74-110 (the tiny-style head, :58-69); encoder:
     oracle/shufflenet.py (parity unpinned, see its header)."""

@@ -11,10 +11,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("YOLO_HIP_LIB") or os.path.join(_HERE, "csrc", "libyolo_hip.so")   # override: A/B runs of two builds
 
-ACT_NONE, ACT_LEAKY01, ACT_RELU6, ACT_RELU = 0, 1, 2, 3
+ACT_NONE, ACT_LEAKY01, ACT_RELU6, ACT_RELU, ACT_SWISH = 0, 1, 2, 3, 4
 DT_BF16, DT_F32 = 0, 1
 OP_CONV, OP_MAXPOOL, OP_SPP, OP_DWCONV, OP_CONV1_NCHW, OP_RESUNIT, OP_STEM, OP_HEAD_DECODE, OP_CONV1_POOL = 1, 2, 3, 4, 5, 6, 7, 8, 9
-OP_MBCONV, OP_CONV_POOL, OP_SHUFFLE, OP_CONV_F32, OP_MAXPOOL_F32 = 10, 11, 12, 13, 14
+OP_MBCONV, OP_CONV_POOL, OP_SHUFFLE, OP_CONV_F32, OP_MAXPOOL_F32, OP_SE = 10, 11, 12, 13, 14, 15
 
 
 class YoloConvDesc(C.Structure):
@@ -72,6 +72,9 @@ SIGNATURES = {
     "yolo_mbconv_supported": (C.c_int, [C.c_int] * 4),
     "yolo_mbconv_fwd": (C.c_int, [C.c_void_p] * 8 + [C.POINTER(YoloMbconvDesc), C.c_void_p]),
     "yolo_dwconv3x3_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 12 + [C.c_void_p]),
+    "yolo_dwconv_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 14 + [C.c_void_p]),
+    "yolo_se_workspace_bytes": (C.c_size_t, [C.c_int] * 2),
+    "yolo_se_fwd": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 8 + [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "yolo_channel_shuffle2_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 11 + [C.c_void_p]),
     "yolo_maxpool_fwd": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 14 + [C.c_void_p]),
     "yolo_spp_fwd": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),

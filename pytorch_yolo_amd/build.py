@@ -27,6 +27,7 @@ SOURCES = {
     "conv_f32.hip": ["-ffp-contract=off"],
     "conv_pp.hip": [],
     "pointwise.hip": [],
+    "efficient.hip": [],
     "preprocess.hip": ["-ffp-contract=off"],
     "nms.hip": ["-ffp-contract=off"],
 }

@@ -632,7 +632,7 @@ int launch_t20(const ConvArgs& a, hipStream_t s) {
 int yolo_conv::launch_t20_3x3(const ConvArgs& a, int force, hipStream_t s) {
   const YoloConvDesc& d = a.d;
   if (d.ksize != 3 || d.stride != 1 || d.pad != 1 || d.upsample2x || d.out_dtype != YOLO_DT_BF16) return 1;
-  if (d.cin % 32 != 0 || d.cout % 128 != 0) return 1;
+  if (d.cin % 32 != 0 || d.cout % 128 != 0 || d.act == YOLO_ACT_SWISH) return 1;   // (the epilogue's min / max form has no swish)
   const size_t npix = (size_t)d.n * d.h * d.w;      // the epilogue addresses y / residual / pre-add copy with 32-bit byte offsets
   if (npix * d.out_c_total * 2 >= kOobOffset || (a.res && npix * d.res_c_total * 2 >= kOobOffset) ||
       (a.aux && npix * d.aux_c_total * 2 >= kOobOffset))

@@ -120,6 +120,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == YOLO_ACT_LEAKY01) return fmaxf(v, 0.1f * v);   // == (v > 0 ? v : 0.1 v) for every input incl. -0, inf, NaN; one instruction less
   if (act == YOLO_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
   if (act == YOLO_ACT_RELU) return fmaxf(v, 0.f);
+  if (act == YOLO_ACT_SWISH) return v / (1.f + expf(-v));   // x * sigmoid(x)
   return v;
 }
 

@@ -665,9 +665,13 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
                "conv: bad output view (cout %d, offset %d, total %d)", d.cout, d.out_c_offset, d.out_c_total);
   YOLO_REQUIRE(d.kpad % 64 == 0 && d.kpad >= d.ksize * d.ksize * d.cin, "conv: kpad %d must be a multiple of 64", d.kpad);
   YOLO_REQUIRE(d.cout_pad % 128 == 0 && d.cout_pad >= d.cout, "conv: cout_pad %d", d.cout_pad);
-  YOLO_REQUIRE(d.ho == (d.h + 2 * d.pad - d.ksize) / d.stride + 1 && d.wo == (d.w + 2 * d.pad - d.ksize) / d.stride + 1,
+  const int ho_std = (d.h + 2 * d.pad - d.ksize) / d.stride + 1, wo_std = (d.w + 2 * d.pad - d.ksize) / d.stride + 1;
+  // one more row / column than the symmetric-pad size = one more zero below / right of the image (TensorFlow "same" padding)
+  YOLO_REQUIRE((d.ho == ho_std || (d.ho == ho_std + 1 && (d.ho - 1) * d.stride - d.pad < d.h)) &&
+                   (d.wo == wo_std || (d.wo == wo_std + 1 && (d.wo - 1) * d.stride - d.pad < d.w)),
                "conv: output size %dx%d inconsistent with input %dx%d k%d s%d p%d", d.ho, d.wo, d.h, d.w, d.ksize,
                d.stride, d.pad);
+  const bool std_out = d.ho == ho_std && d.wo == wo_std;
   if (res) YOLO_REQUIRE(d.res_c_total % 4 == 0 && d.res_c_offset % 4 == 0 && !d.upsample2x, "conv: bad residual view");
   if (y_aux) YOLO_REQUIRE(d.aux_c_total % 4 == 0 && d.aux_c_offset % 4 == 0, "conv: bad aux view");
   const size_t x_bytes = (size_t)d.n * d.h * d.w * d.in_c_total * 2;
@@ -709,11 +713,11 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
   // 3x3/s1 layers whose maps 20x20 tiles cover and fill the chip with (conv3x3_t20.hip).  YOLO_CONV_PP bit 16: every layer the
   // kernel can compute, bit 32: ... with 256 couts per workgroup where cout allows, bit 64: never, bit 128: every such layer with
   // the second form (4 waves, weights straight to registers, two workgroups per CU).
-  if (epi && conv_variant_override < 0 && !(conv_pp_mask & 64) && a.splits <= 1) {
+  if (epi && std_out && conv_variant_override < 0 && !(conv_pp_mask & 64) && a.splits <= 1) {
     const int rc = launch_t20_3x3(a, (conv_pp_mask & 16 ? 1 : 0) | (conv_pp_mask & 32 ? 3 : 0) | (conv_pp_mask & 128 ? 5 : 0), s);
     if (rc != 1) return rc;
   }
-  if (epi && !(conv_debug_flags & 32) && conv_variant_override < 0 && !(conv_pp_mask & 8)) {   // large 3x3/s1 maps: halo-staged kernel
+  if (epi && std_out && !(conv_debug_flags & 32) && conv_variant_override < 0 && !(conv_pp_mask & 8)) {   // large 3x3/s1 maps: halo-staged kernel
     a.n_tiles = 0;
     const int rc = launch_halo3x3(a, s);
     if (rc != 1) return rc;

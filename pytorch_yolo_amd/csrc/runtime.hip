@@ -42,8 +42,14 @@ extern "C" int yolo_run_ops(const YoloOp* ops, int n_ops, yolo_stream_t s) {
         rc = yolo_spp_fwd(o.y, d.n, d.h, d.w, d.cin, s);
         break;
       case YOLO_OP_DWCONV:
-        rc = yolo_dwconv3x3_fwd(o.x, (const float*)o.w, o.bias, o.y, d.n, d.h, d.w, d.cin, d.in_c_total, d.in_c_offset, d.ho,
-                                d.wo, d.out_c_total, d.out_c_offset, d.stride, d.act, s);
+        rc = d.ksize == 0 ? yolo_dwconv3x3_fwd(o.x, (const float*)o.w, o.bias, o.y, d.n, d.h, d.w, d.cin, d.in_c_total, d.in_c_offset, d.ho,
+                                               d.wo, d.out_c_total, d.out_c_offset, d.stride, d.act, s)
+                          : yolo_dwconv_fwd(o.x, (const float*)o.w, o.bias, o.y, d.n, d.h, d.w, d.cin, d.in_c_total, d.in_c_offset, d.ho,
+                                            d.wo, d.out_c_total, d.out_c_offset, d.ksize, d.stride, d.pad, d.act, s);
+        break;
+      case YOLO_OP_SE:
+        rc = yolo_se_fwd(o.x, o.y, d.n, d.h, d.w, d.cin, d.in_c_total, d.in_c_offset, d.out_c_total, d.out_c_offset, (const float*)o.w,
+                         o.bias, (const float*)o.w_pre, o.bias_pre, o.kpad_pre, o.workspace, o.ws_bytes, s);
         break;
       case YOLO_OP_RESUNIT:
         rc = yolo_resunit_fwd(o.x, o.w_pre, o.bias_pre, o.w, o.bias, o.y, o.y_aux, &d, o.kpad_pre, o.cout_pad_pre, s);

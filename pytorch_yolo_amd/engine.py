@@ -27,7 +27,7 @@ from typing import List, Optional
 import torch
 
 from . import kernels as K
-from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU, ACT_RELU6, DT_BF16, DT_F32, OP_CONV, OP_CONV1_NCHW, OP_CONV_F32, OP_DWCONV,
+from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SWISH, DT_BF16, DT_F32, OP_SE, OP_CONV, OP_CONV1_NCHW, OP_CONV_F32, OP_DWCONV,
                    OP_CONV1_POOL, OP_CONV_POOL, OP_MAXPOOL_F32, OP_MBCONV, OP_SHUFFLE, OP_HEAD_DECODE, OP_MAXPOOL, OP_RESUNIT, OP_SPP,
                    OP_STEM, YoloOp)
 
@@ -91,8 +91,15 @@ class Recorder:
         return node
 
     # weight = (w_oihw f32, bias f32) already BN-folded; act in {'leaky','relu6','none'}
+    @staticmethod
+    def tf_same(size: int, k: int, stride: int):
+        """TensorFlow "same" padding as efficientnet_pytorch 0.2.0's Conv2dSamePadding computes it: output ceil(size / stride),
+        total pad max((out - 1) stride + k - size, 0), the odd one BELOW / RIGHT.  Returns (out, leading pad)."""
+        out = -(-size // stride)
+        return out, max((out - 1) * stride + k - size, 0) // 2
+
     def conv(self, x: Sym, weight, stride=1, act="leaky", residual: Sym = None, want_preadd=False, f32_out=False, pad=None,
-             name=None):
+             name=None, tf_same=False):
         w, _ = weight
         cout, cin_w, k, _ = w.shape
         if cin_w > x.c:
@@ -100,6 +107,10 @@ class Recorder:
         same = (k - 1) // 2
         pad = same if pad is None else pad
         ho, wo = (x.h + 2 * pad - k) // stride + 1, (x.w + 2 * pad - k) // stride + 1
+        if tf_same:
+            (ho, pad), (wo, pad_w) = self.tf_same(x.h, k, stride), self.tf_same(x.w, k, stride)
+            if pad != pad_w:
+                raise RuntimeError("tf_same conv: the two axes need different leading pads (one odd, one even size): not supported")
         if not f32_out and cout % 8:
             raise RuntimeError(f"internal conv width {cout} is not a multiple of 8 (unsupported kernels_divider)")
         y = Sym(x.n, ho, wo, cout, f32=f32_out)
@@ -112,11 +123,30 @@ class Recorder:
             self.nodes[-1].attrs["pad"] = pad            # (SqueezeNet's unpadded first conv; no fused form takes it)
         return (y, outs[1]) if want_preadd else y
 
-    def dwconv(self, x: Sym, weight, stride=1, act="relu6"):
-        w, _ = weight                                   # [c,1,3,3]
-        ho, wo = (x.h - 1) // stride + 1, (x.w - 1) // stride + 1
+    def dwconv(self, x: Sym, weight, stride=1, act="relu6", tf_same=False):
+        """Depthwise k x k conv.  Default: 3x3 / pad 1 (MobileNetV2).  ``tf_same``: k = 3 or 5 with TensorFlow "same" padding
+        (EfficientNet-B0's MBConvBlock._depthwise_conv) - the general kernel, which also takes the swish activation."""
+        w, _ = weight                                   # [c,1,k,k]
+        k = w.shape[2]
+        if not tf_same:
+            if k != 3:
+                raise RuntimeError("dwconv: only 3x3 with torch-style pad 1; pass tf_same=True for k = 5")
+            ho, wo = (x.h - 1) // stride + 1, (x.w - 1) // stride + 1
+            y = Sym(x.n, ho, wo, x.c)
+            self._add("dwconv", [x], [y], weight=weight, stride=stride, act=act)
+            return y
+        (ho, pad), (wo, pad_w) = self.tf_same(x.h, k, stride), self.tf_same(x.w, k, stride)
+        if pad != pad_w:
+            raise RuntimeError("tf_same dwconv: the two axes need different leading pads: not supported")
         y = Sym(x.n, ho, wo, x.c)
-        self._add("dwconv", [x], [y], weight=weight, stride=stride, act=act)
+        self._add("dwconv", [x], [y], weight=weight, stride=stride, act=act, ksize=k, pad=pad)
+        return y
+
+    def se(self, x: Sym, w1, b1, w2, b2):
+        """Squeeze-and-excitation: y = x * sigmoid(W2 swish(W1 mean_hw(x) + b1) + b2) (efficientnet_pytorch MBConvBlock).
+        w1: [sq, c] (or [sq, c, 1, 1]), w2: [c, sq]."""
+        y = Sym(x.n, x.h, x.w, x.c)
+        self._add("se", [x], [y], w1=w1, b1=b1, w2=w2, b2=b2)
         return y
 
     def maxpool(self, x: Sym, size, stride, pad=None, ceil_mode=False):
@@ -174,7 +204,7 @@ class Recorder:
         self._add("head", [x], [])
 
 
-_ACT = {"leaky": ACT_LEAKY01, "relu6": ACT_RELU6, "relu": ACT_RELU, "none": ACT_NONE}
+_ACT = {"leaky": ACT_LEAKY01, "relu6": ACT_RELU6, "relu": ACT_RELU, "none": ACT_NONE, "swish": ACT_SWISH}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -604,6 +634,8 @@ class Plan:
                                 out_dtype=DT_F32 if y.f32 else DT_BF16, pad=nd.attrs.get("pad"),
                                 res=(res.buf.c_total, res.c_offset) if res is not None else (0, 0),
                                 aux=(aux.buf.c_total, aux.c_offset) if aux is not None else (0, 0))
+                if up is None and pooled is None:
+                    d.ho, d.wo = y.h, y.w                  # (tf_same convs: one more row / column than the symmetric-pad formula)
                 op = YoloOp()
                 fused_first = self.fused_input and x is self.rec.input
                 if fused_first:
@@ -631,7 +663,8 @@ class Plan:
             elif nd.kind == "dwconv":
                 x, y = nd.srcs[0], nd.outs[0]
                 w, b = nd.attrs["weight"]
-                w9c = self._dev(w.detach().float().reshape(x.c, 9).t().contiguous())
+                kk = w.shape[2] * w.shape[3]
+                w9c = self._dev(w.detach().float().reshape(x.c, kk).t().contiguous())
                 bb = self._dev(b.detach().float().contiguous())
                 op = YoloOp()
                 op.kind = OP_DWCONV
@@ -640,6 +673,24 @@ class Plan:
                 d.n, d.h, d.w, d.cin = x.n, x.h, x.w, x.c
                 d.in_c_total, d.in_c_offset, d.ho, d.wo = x.buf.c_total, x.c_offset, y.h, y.w
                 d.out_c_total, d.out_c_offset, d.stride, d.act = y.buf.c_total, y.c_offset, nd.attrs["stride"], _ACT[nd.attrs["act"]]
+                d.ksize, d.pad = nd.attrs.get("ksize", 0), nd.attrs.get("pad", 0)      # ksize 0: the 3x3 / pad 1 strip kernel
+                ops.append(op); op_nodes.append(nd)
+            elif nd.kind == "se":
+                x, y = nd.srcs[0], nd.outs[0]
+                sq = nd.attrs["w1"].shape[0]
+                w1 = self._dev(nd.attrs["w1"].detach().float().reshape(sq, x.c).contiguous())
+                w2 = self._dev(nd.attrs["w2"].detach().float().reshape(x.c, sq).contiguous())
+                b1, b2 = self._dev(nd.attrs["b1"].detach().float().contiguous()), self._dev(nd.attrs["b2"].detach().float().contiguous())
+                ws = self._dev(torch.zeros(K.se_workspace_bytes(x.n, x.c) // 4, dtype=torch.float32))
+                op = YoloOp()
+                op.kind = OP_SE
+                op.x, op.y, op.w, op.bias = x.buf.tensor.data_ptr(), y.buf.tensor.data_ptr(), w1.data_ptr(), b1.data_ptr()
+                op.w_pre, op.bias_pre, op.kpad_pre = w2.data_ptr(), b2.data_ptr(), sq
+                op.workspace, op.ws_bytes = ws.data_ptr(), ws.numel() * 4
+                d = op.conv
+                d.n, d.h, d.w, d.cin = x.n, x.h, x.w, x.c
+                d.in_c_total, d.in_c_offset, d.ho, d.wo = x.buf.c_total, x.c_offset, y.h, y.w
+                d.out_c_total, d.out_c_offset = y.buf.c_total, y.c_offset
                 ops.append(op); op_nodes.append(nd)
             elif nd.kind == "shuffle":
                 a_, b_, y = nd.srcs[0], nd.srcs[1], nd.outs[0]
@@ -723,7 +774,7 @@ class Plan:
                     d.out_c_total, d.out_c_offset = y.buf.c_total, out_off
                     d.ksize, d.stride, d.pad, d.upsample2x = k, st, pad, dil
                     ops.append(op); op_nodes.append(nd)
-            elif nd.kind in ("dwconv", "shuffle"):
+            elif nd.kind in ("dwconv", "shuffle", "se"):
                 raise NotImplementedError("precision='fp32' covers the Darknet families (YOLOv3-SPP / -tiny / YOLOv3 / Lite); "
                                           f"no fp32 kernel for '{nd.kind}' layers")
         self.n_ops = len(ops)
@@ -837,6 +888,8 @@ class Plan:
                 total += m_in * d.cin * 2 + m_out * d.cout * 2
             elif op.kind in (OP_MAXPOOL, OP_DWCONV, OP_MAXPOOL_F32):
                 total += (m_in + m_out) * d.cin * (4 if op.kind == OP_MAXPOOL_F32 else 2)
+            elif op.kind == OP_SE:
+                total += 3.0 * m_in * d.cin * 2                                      # pooled once, read again for the rescale, written
             elif op.kind == OP_SPP:
                 total += m_in * d.cin * 2 * 4                                        # reads c, writes the three pooled copies
             elif op.kind == OP_SHUFFLE:

@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU6, DT_BF16, DT_F32, YoloConvDesc, YoloMbconvDesc,
                    check, load)
 
-__all__ = ["stream_ptr", "pack_input", "conv2d", "stem", "resunit", "resunit_supported", "maxpool", "spp", "dwconv3x3", "mbconv", "mbconv_supported", "pack_mbconv", "conv3x3_pool", "conv3x3_pool_supported", "conv2d_splitk", "conv2d_splitk_plan", "decode", "head_decode", "head_decode_supported",
+__all__ = ["stream_ptr", "pack_input", "conv2d", "stem", "resunit", "resunit_supported", "maxpool", "spp", "dwconv3x3", "dwconv", "se", "se_workspace_bytes", "mbconv", "mbconv_supported", "pack_mbconv", "conv3x3_pool", "conv3x3_pool_supported", "conv2d_splitk", "conv2d_splitk_plan", "decode", "head_decode", "head_decode_supported",
            "nms_merge", "pack_conv_weight", "roundup", "run_ops"]
 
 
@@ -180,6 +180,27 @@ def spp(buf, *, n, h, w, c):
     _need_cuda(buf)
     check(load().yolo_spp_fwd(_ptr(buf), n, h, w, c, stream_ptr()), "spp")
     return buf
+
+
+def se_workspace_bytes(n, c) -> int:
+    return int(load().yolo_se_workspace_bytes(n, c))
+
+
+def dwconv(x, wkc, bias, y, *, n, h, w, c, in_view, out_view, ho, wo, ksize, stride, pad, act):
+    """Depthwise k x k (3 or 5) conv with an explicit leading pad (yolo_dwconv_fwd); wkc: f32 [k*k][c]."""
+    _need_cuda(x, wkc, bias, y)
+    check(load().yolo_dwconv_fwd(_ptr(x), _ptr(wkc), _ptr(bias), _ptr(y), n, h, w, c, in_view[0], in_view[1], ho, wo, out_view[0],
+                                 out_view[1], ksize, stride, pad, act, stream_ptr()), "dwconv")
+    return y
+
+
+def se(x, y, w1, b1, w2, b2, workspace, *, n, h, w, c, in_view, out_view):
+    """Squeeze-and-excitation (yolo_se_fwd): w1 f32 [sq][c], w2 f32 [c][sq]."""
+    _need_cuda(x, y, w1, b1, w2, b2, workspace)
+    check(load().yolo_se_fwd(_ptr(x), _ptr(y), n, h, w, c, in_view[0], in_view[1], out_view[0], out_view[1], _ptr(w1), _ptr(b1),
+                             _ptr(w2), _ptr(b2), w1.shape[0], _ptr(workspace), workspace.numel() * workspace.element_size(),
+                             stream_ptr()), "se")
+    return y
 
 
 def dwconv3x3(x, w9c, bias, y, *, n, h, w, c, in_view, out_view, stride, act):

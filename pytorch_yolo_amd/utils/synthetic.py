@@ -120,8 +120,10 @@ def synth_state_dict(template, seed: int = 1234, n_class: int | None = None):
                 val = (val + sh).astype(np.float32)
         elif key.endswith(".weight"):  # 1-D scale of a BN without "batch_norm" in its name (MobileNetV2 keys)
             val = (rng.uniform(0.5, 1.5, shape) * 0.917).astype(np.float32)
-            if _MBV2_PROJECT_BN.search(key):        # linear-bottleneck BN feeding an identity add
-                val = (val * 0.5).astype(np.float32)
+            if _MBV2_PROJECT_BN.search(key) or key.endswith("._bn2.weight"):   # linear-bottleneck BN feeding an identity add
+                val = (val * 0.5).astype(np.float32)                             # (MobileNetV2 / EfficientNet-B0 project BN)
+            elif key.endswith("._bn0.weight") or key.endswith("._bn1.weight") or ".stem.1.weight" in key:
+                val = (val * 1.6).astype(np.float32)   # swish keeps ~0.36 of a unit normal's power, squeeze-excite ~0.3 more
         else:
             val = (rng.standard_normal(shape) * 0.1).astype(np.float32)
         out[key] = torch.from_numpy(val)

@@ -1639,3 +1639,105 @@ def test_t20_conv_kernel(case):
     diff = (y.float() - y0.float()).abs()
     assert float(diff.max()) <= 2 ** -6 * max(1.0, float(y0.float().abs().max())), "differs from the shipped kernels by more than 2 bf16 ulp"
     assert float((diff > 0).float().mean()) < 0.25   # same operands, another fp32 summation order: a minority of last-bit flips
+
+
+# ------------------------------------------------------------------------------------------------
+# EfficientNet-B0 encoder (third of three): swish, depthwise 3x3 / 5x5 with TensorFlow "same" padding,
+# squeeze-and-excitation.  torch is the reference for the kernels; the encoder oracle restates the published architecture
+# (efficientnet_pytorch absent: parity unpinned, oracle/efficientnet.py).
+@pytest.mark.parametrize("k,stride,h,w,c,act", [(3, 1, 20, 26, 32, "swish"), (3, 2, 26, 26, 96, "swish"), (5, 2, 52, 52, 144, "swish"),
+                                                (5, 1, 13, 13, 672, "swish"), (5, 2, 13, 13, 40, "relu6"), (3, 2, 27, 27, 24, "none")])
+def test_dwconv_general(k, stride, h, w, c, act):
+    """yolo_dwconv_fwd against fp32 torch on the same bf16 input: both kernel sizes and strides, even sizes (the odd pad row /
+    column below / right) and odd ones (symmetric), channel-offset views on both sides."""
+    from oracle.efficientnet import conv_same, swish
+    from pytorch_yolo_amd import kernels as K
+    from pytorch_yolo_amd._lib import ACT_NONE, ACT_RELU6, ACT_SWISH
+    from pytorch_yolo_amd.engine import Recorder
+    n = 2
+    g = torch.Generator().manual_seed(k * 100 + h + c)
+    x = torch.randn(n, c, h, w, generator=g)
+    wt = torch.randn(c, 1, k, k, generator=g) * 0.3
+    b = torch.randn(c, generator=g) * 0.1
+    (ho, pad), (wo, _) = Recorder.tf_same(h, k, stride), Recorder.tf_same(w, k, stride)
+    xin = torch.zeros(n, h, w, c + 16, dtype=torch.bfloat16, device=DEV)
+    xin[..., 8:8 + c] = _nhwc(x)
+    y = torch.full((n, ho, wo, c + 8), -77.0, dtype=torch.bfloat16, device=DEV)
+    K.dwconv(xin, wt.reshape(c, k * k).t().contiguous().to(DEV), b.to(DEV), y, n=n, h=h, w=w, c=c, in_view=(c + 16, 8),
+             out_view=(c + 8, 8), ho=ho, wo=wo, ksize=k, stride=stride, pad=pad, act={"swish": ACT_SWISH, "relu6": ACT_RELU6, "none": ACT_NONE}[act])
+    ref = conv_same(_bf16r(x), wt, b, stride=stride, groups=c)
+    ref = {"swish": swish, "relu6": F.relu6, "none": lambda t: t}[act](ref)
+    assert ref.shape[-2:] == (ho, wo)
+    torch.testing.assert_close(_nchw(y[..., 8:]), ref, rtol=1e-2, atol=1e-2)
+    assert torch.all(y[..., :8] == -77.0)
+
+
+@pytest.mark.parametrize("n,h,w,c,sq", [(2, 13, 13, 672, 28), (3, 52, 52, 96, 4), (1, 104, 104, 32, 8), (2, 7, 9, 1152, 48)])
+def test_squeeze_excite(n, h, w, c, sq):
+    """yolo_se_fwd against torch: y = x * sigmoid(W2 swish(W1 mean(x) + b1) + b2), in place of nothing (separate output view)."""
+    from oracle.efficientnet import swish
+    from pytorch_yolo_amd import kernels as K
+    g = torch.Generator().manual_seed(c + sq)
+    x = torch.randn(n, c, h, w, generator=g)
+    w1, b1 = torch.randn(sq, c, generator=g) * (1.0 / c) ** 0.5, torch.randn(sq, generator=g) * 0.1
+    w2, b2 = torch.randn(c, sq, generator=g) * (1.0 / sq) ** 0.5, torch.randn(c, generator=g) * 0.1
+    xin = torch.zeros(n, h, w, c + 8, dtype=torch.bfloat16, device=DEV)
+    xin[..., 8:] = _nhwc(x)
+    y = torch.full((n, h, w, c + 16), -77.0, dtype=torch.bfloat16, device=DEV)
+    ws = torch.zeros(K.se_workspace_bytes(n, c) // 4, dtype=torch.float32, device=DEV)
+    K.se(xin, y, w1.to(DEV), b1.to(DEV), w2.to(DEV), b2.to(DEV), ws, n=n, h=h, w=w, c=c, in_view=(c + 8, 8), out_view=(c + 16, 16))
+    xr = _bf16r(x)
+    s_ = F.conv2d(swish(F.conv2d(F.adaptive_avg_pool2d(xr, 1), w1[:, :, None, None], b1)), w2[:, :, None, None], b2)
+    ref = torch.sigmoid(s_) * xr
+    torch.testing.assert_close(_nchw(y[..., 16:]), ref, rtol=1e-2, atol=1e-2)
+    assert torch.all(y[..., :16] == -77.0)
+    torch.testing.assert_close(ws[:n * c].cpu().reshape(n, c), xr.mean((2, 3)), rtol=1e-4, atol=1e-5)   # the pooled means themselves
+
+
+@pytest.mark.parametrize("h,w,cin,cout,k,stride", [(32, 48, 8, 32, 3, 2), (26, 26, 96, 24, 1, 1), (40, 40, 64, 96, 3, 2)])
+def test_conv_tf_same_and_swish(h, w, cin, cout, k, stride):
+    """yolo_conv2d_fwd with the output one row / column beyond the symmetric-pad size (the window of the last row hangs over
+    the edge by one more zero: TensorFlow "same" at stride 2 on an even map) and the swish epilogue."""
+    from oracle.efficientnet import conv_same, swish
+    from pytorch_yolo_amd import kernels as K
+    from pytorch_yolo_amd._lib import ACT_SWISH
+    from pytorch_yolo_amd.engine import Recorder
+    n = 2
+    g = torch.Generator().manual_seed(h + cin)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    (ho, pad), (wo, _) = Recorder.tf_same(h, k, stride), Recorder.tf_same(w, k, stride)
+    wp, bp, kpad, cout_pad = K.pack_conv_weight(wt, bias, cin)
+    d = K.conv_desc(n=n, h=h, w=w, cin=cin, in_c_total=cin, in_c_offset=0, cout=cout, out_c_total=cout, out_c_offset=0, ksize=k,
+                    stride=stride, act=ACT_SWISH, kpad=kpad, cout_pad=cout_pad, pad=pad)
+    d.ho, d.wo = ho, wo
+    y = torch.zeros(n, ho, wo, cout, dtype=torch.bfloat16, device=DEV)
+    K.conv2d(_nhwc(x), wp.to(DEV), bp.to(DEV), y, d)
+    ref = swish(conv_same(_bf16r(x), _bf16r(wt), bias, stride=stride))
+    assert ref.shape[-2:] == (ho, wo)
+    torch.testing.assert_close(_nchw(y), ref, rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 96, 128), (1, 416, 416), (1, 160, 224)])
+def test_efficientnet_variant_vs_oracle(n, h, w):
+    """YOLOv3TinyEfficient (reference models/yolov3_tiny_efficient.py): 16 MBConv blocks with swish, 3x3 / 5x5 depthwise convs under
+    TensorFlow "same" padding and squeeze-excite, routes after blocks 11 and 16, the tiny-style head.  (Sizes are multiples of
+    32: with ceil-mode "same" convs anything else breaks the reference's own upsample + concat; odd maps are covered at kernel
+    level by test_dwconv_general / test_conv_tf_same_and_swish.)"""
+    from oracle import models as om
+    from pytorch_yolo_amd import YOLOv3TinyEfficient
+    from pytorch_yolo_amd.utils.synthetic import synth_images, synth_state_dict
+    model = YOLOv3TinyEfficient(n_class=3).eval()
+    sd = synth_state_dict(model.state_dict(), 5, n_class=3)
+    model.load_state_dict(sd)
+    x = synth_images(n, h, w, 3)
+    with torch.no_grad():
+        io_ref, p_ref = om.tiny_efficient_forward(sd, x, om.TINY_ANCHORS, 3)
+        io, p = model.to(DEV)(x.to(DEV))
+    assert io.shape == io_ref.shape and [tuple(q.shape) for q in p] == [tuple(q.shape) for q in p_ref]
+    for k_, (a, b) in enumerate(zip(p, p_ref)):
+        rel = float((a.cpu().double() - b.double()).norm() / b.double().norm())
+        print(f"[efficient_{h}x{w}] head {k_} raw logits: relative error {rel:.4f}")
+        assert rel < 0.03
+    _assert_model_close(io.cpu(), io_ref, f"efficient_{h}x{w}", score_max=4e-2, score_rms=5e-3, box_rel_tol=0.04)
