@@ -405,6 +405,7 @@ constexpr int kV2Pitch = 528;                        // fp32 staging row: 128 co
 constexpr int kV2Lds = 2 * kHaloB + kV2Hofs;
 static_assert(2 * 32 * kV2Pitch <= 2 * kHaloB, "epilogue buffers reuse the halo region");
 
+template <int XD>   // pixel fragments in flight: XD registers sets in rotation, XD - 1 patches ahead of the MFMAs
 __global__ __launch_bounds__(256, 2) void conv3x3_t20v2_kernel(const ConvArgs a) {
   constexpr int CT = 128, NW = 4, NP = 25, HPT = 8;
   __shared__ __attribute__((aligned(16))) char smem[kV2Lds];
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_t20v2_kernel(const ConvArgs a)
   };
 
   const int nch = d.cin / 32;
-  bf16x8 wf[3][2], xf[3];
+  bf16x8 wf[3][2], xf[XD];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     wf[0][i] = wload(0, 0, i);
@@ -503,14 +504,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_t20v2_kernel(const ConvArgs a)
       }
       const uint32_t am = A[par], am_n = A[par_n];
       if constexpr (tap == 0) {                        // a new halo buffer: nothing of it could be fetched before the barrier
-        xf[0] = xread(0, 0, am);
-        xf[1] = xread(1, 0, am);
+#pragma unroll
+        for (int j = 0; j < XD - 1; ++j) xf[j] = xread(j, 0, am);
       }
       static_for<NP>([&](auto jc) {
         constexpr int jj = decltype(jc)::value;
-        if constexpr (jj + 2 < NP) xf[(jj + 2 + tap) % 3] = xread(jj + 2, tap, am);
-        else if constexpr (tap < 8) xf[(jj + 2 + tap) % 3] = xread(jj + 2 - NP, tap + 1, am_n);   // the next step's first two
-        static_for<2>([&](auto ic) { mfma(ic, jc, wf[tap % 3][decltype(ic)::value], xf[(jj + tap) % 3]); });
+        // rotation: patch jj of tap t lives in xf[(jj + t * NP) % XD]; NP % XD == 1 for XD = 3, 4 (25 = 24 + 1), so the slot of
+        // the next tap's patch j is (NP + j + t * NP) % XD = the slot "patch NP + j of this tap" would take
+        constexpr int R = (tap * NP) % XD;
+        if constexpr (jj + XD - 1 < NP) xf[(jj + XD - 1 + R) % XD] = xread(jj + XD - 1, tap, am);
+        else if constexpr (tap < 8) xf[(jj + XD - 1 + R) % XD] = xread(jj + XD - 1 - NP, tap + 1, am_n);   // the next step's first ones
+        static_for<2>([&](auto ic) { mfma(ic, jc, wf[tap % 3][decltype(ic)::value], xf[(jj + R) % XD]); });
       });
       if constexpr (tap == 8) {
         wait_vmcnt<2>();                               // everything but the two youngest weight loads: the next halo has landed
@@ -610,7 +614,8 @@ int launch_t20v2(const ConvArgs& a, hipStream_t s) {
   b.n_tiles = a.d.cout / 128;
   const long grid = (long)a.d.n * ((a.d.h + kT20 - 1) / kT20) * ((a.d.w + kT20 - 1) / kT20) * b.n_tiles;
   if (grid > 0x7fffffffL) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv grid too large");
-  hipLaunchKernelGGL(conv3x3_t20v2_kernel, dim3((unsigned)grid), dim3(256), 0, s, b);
+  if (a.debug & 64) hipLaunchKernelGGL(conv3x3_t20v2_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, b);   // A/B: four pixel fragments in flight
+  else hipLaunchKernelGGL(conv3x3_t20v2_kernel<3>, dim3((unsigned)grid), dim3(256), 0, s, b);
   return yolo_check_launch("yolo_conv2d_fwd(t20v2)");
 }
 

@@ -23,7 +23,7 @@ DEFAULT = ["16,40,40,256,512,3,1,1", "16,20,20,512,1024,3,1,1", "16,80,80,128,25
 
 def main():
     args = sys.argv[1:]
-    rounds, reps, arms = 5, 20, [0, 4]
+    rounds, reps, arms, knob = 5, 20, [0, 4], 2
     while args and args[0].startswith("--"):
         if args[0] == "--rounds":
             rounds = int(args[1])
@@ -31,6 +31,8 @@ def main():
             reps = int(args[1])
         elif args[0] == "--arms":
             arms = [int(v) for v in args[1].split(",")]
+        elif args[0] == "--knob":                         # 2: YOLO_CONV_PP (default), 1: YOLO_CONV_DEBUG, 0: YOLO_CONV_VARIANT
+            knob = int(args[1])
         args = args[2:]
     lib = load()
     dev = "cuda:0"
@@ -51,13 +53,13 @@ def main():
         ys = {a: torch.zeros(n, ho, wo, cout, dtype=torch.bfloat16, device=dev) for a in arms}
         times = {a: [] for a in arms}
         for a in arms:                                   # warm-up + outputs
-            lib.yolo_set_tuning(2, a)
+            lib.yolo_set_tuning(knob, a)
             for _ in range(3):
                 K.conv2d(x, wp, bp, ys[a], d, residual=res)
         torch.cuda.synchronize()
         for _ in range(rounds):
             for a in arms:
-                lib.yolo_set_tuning(2, a)
+                lib.yolo_set_tuning(knob, a)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(reps):
@@ -65,7 +67,7 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 times[a].append(e0.elapsed_time(e1) / reps)
-        lib.yolo_set_tuning(2, 0)
+        lib.yolo_set_tuning(knob, 0 if knob else -1)
         fl = 2.0 * n * ho * wo * cout * k * k * cin
         row = f"{spec:28s} M={n * ho * wo:7d} N={cout:5d} K={k * k * cin:5d}"
         for a in arms:
