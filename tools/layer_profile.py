@@ -92,8 +92,8 @@ def main():
             by = d.n * d.h * d.w * d.cin * 2 + M * d.cout * 2
             print(f"{i:3d} {'mbconv':7} {M:9d} {d.cout:5d} {hid:5d} 3 {d.stride:1d} {ms:8.4f} {fl / ms / 1e9:8.1f} {by / ms / 1e6:7.0f}  {'res' if d.res_c_total else ''}")
         else:
-            kind = {OP_MAXPOOL: "pool", OP_SPP: "spp", OP_DWCONV: "dwconv"}[op.kind]
-            by = d.n * d.h * d.w * d.cin * 2 * (4 if op.kind == OP_SPP else 2)
+            kind = {OP_MAXPOOL: "pool", OP_SPP: "spp", OP_DWCONV: "dwconv", 12: "shuffle", 15: "se"}.get(op.kind, f"op{op.kind}")
+            by = d.n * d.h * d.w * d.cin * 2 * (4 if op.kind == OP_SPP else 3 if op.kind == 15 else 2)
             print(f"{i:3d} {kind:7} {d.n * d.h * d.w:9d} {d.cin:5d} {'':5} {d.ksize:1d} {d.stride:1d} {ms:8.4f} {'':8} {by / ms / 1e6:7.0f}")
     print(f"total {tot_ms:.3f} ms  conv {tot_fl / 1e12:.3f} TFLOP -> {tot_fl / tot_ms / 1e9:.1f} TFLOP/s over the per-op sum")
 
