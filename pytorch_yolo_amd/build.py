@@ -26,6 +26,7 @@ SOURCES = {
     "conv_small.hip": [],
     "conv_f32.hip": ["-ffp-contract=off"],
     "conv_pp.hip": [],
+    "conv1x1_stream.hip": [],
     "pointwise.hip": [],
     "efficient.hip": [],
     "preprocess.hip": ["-ffp-contract=off"],

@@ -717,6 +717,12 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
     const int rc = launch_t20_3x3(a, (conv_pp_mask & 16 ? 1 : 0) | (conv_pp_mask & 32 ? 3 : 0) | (conv_pp_mask & 128 ? 5 : 0), s);
     if (rc != 1) return rc;
   }
+  // short-K 1x1 layers on the large maps: weight-stationary streaming kernel (conv1x1_stream.hip).  YOLO_CONV_PP bit 1024: never,
+  // bit 2048: every layer it can compute.
+  if (epi && std_out && d.ksize == 1 && conv_variant_override < 0 && !(conv_pp_mask & 1024) && a.splits <= 1) {
+    const int rc = launch_stream1x1(a, conv_pp_mask & 2048 ? 1 : 0, s);
+    if (rc != 1) return rc;
+  }
   if (epi && std_out && !(conv_debug_flags & 32) && conv_variant_override < 0 && !(conv_pp_mask & 8)) {   // large 3x3/s1 maps: halo-staged kernel
     a.n_tiles = 0;
     const int rc = launch_halo3x3(a, s);

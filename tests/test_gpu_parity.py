@@ -1741,3 +1741,43 @@ def test_efficientnet_variant_vs_oracle(n, h, w):
         print(f"[efficient_{h}x{w}] head {k_} raw logits: relative error {rel:.4f}")
         assert rel < 0.03
     _assert_model_close(io.cpu(), io_ref, f"efficient_{h}x{w}", score_max=4e-2, score_rms=5e-3, box_rel_tol=0.04)
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,act", [(2, 80, 80, 256, 128, "leaky"), (1, 160, 160, 128, 64, "leaky"), (3, 37, 41, 128, 128, "none"),
+                                              (1, 20, 20, 256, 64, "relu6"), (2, 13, 13, 256, 128, "swish")])
+def test_conv1x1_stream_kernel(n, h, w, cin, cout, act):
+    """conv1x1_stream.hip (weights stationary in registers, persistent workgroups, whole-K pixel tiles by LDS-DMA) forced onto
+    every layer it takes (YOLO_CONV_PP bit 2048): against fp32 torch on the same bf16-rounded operands, channel-offset views on
+    both sides, a last tile that is partly beyond the tensor, and the tiled kernel's result within one bf16 ulp."""
+    from oracle.efficientnet import swish
+    from pytorch_yolo_amd import kernels as K
+    from pytorch_yolo_amd._lib import ACT_LEAKY01, ACT_NONE, ACT_RELU6, ACT_SWISH, load
+    g = torch.Generator().manual_seed(h * 7 + cin)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    xin = torch.zeros(n, h, w, cin + 16, dtype=torch.bfloat16, device=DEV)
+    xin[..., 8:8 + cin] = _nhwc(x)
+    wp, bp, kpad, cout_pad = K.pack_conv_weight(wt, bias, cin)
+    code = {"leaky": ACT_LEAKY01, "none": ACT_NONE, "relu6": ACT_RELU6, "swish": ACT_SWISH}[act]
+    d = K.conv_desc(n=n, h=h, w=w, cin=cin, in_c_total=cin + 16, in_c_offset=8, cout=cout, out_c_total=cout + 8, out_c_offset=8,
+                    ksize=1, stride=1, act=code, kpad=kpad, cout_pad=cout_pad)
+    lib = load()
+    outs = {}
+    old = lib.yolo_set_tuning(2, 0)
+    try:
+        for arm in (1024, 2048):
+            lib.yolo_set_tuning(2, arm)
+            y = torch.full((n, h, w, cout + 8), -77.0, dtype=torch.bfloat16, device=DEV)
+            K.conv2d(xin, wp.to(DEV), bp.to(DEV), y, d)
+            torch.cuda.synchronize()
+            outs[arm] = y
+    finally:
+        lib.yolo_set_tuning(2, old)
+    ref = F.conv2d(_bf16r(x), _bf16r(wt), bias)
+    ref = {"leaky": lambda t: F.leaky_relu(t, 0.1), "none": lambda t: t, "relu6": F.relu6, "swish": swish}[act](ref)
+    y = outs[2048]
+    torch.testing.assert_close(_nchw(y[..., 8:]), ref, rtol=1e-2, atol=1e-2)
+    assert torch.all(y[..., :8] == -77.0)
+    diff = (y.float() - outs[1024].float()).abs()
+    assert float(diff.max()) <= 2 ** -6 * max(1.0, float(y.float().abs().max()))
