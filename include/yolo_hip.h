@@ -138,8 +138,10 @@ YOLO_API int yolo_dwconv_fwd(const void* x, const float* w, const float* bias, v
 
 /* ---- squeeze-and-excitation of an MBConvBlock (efficientnet_pytorch 0.2.0 model.py, used through
  *      models/yolov3_tiny_efficient.py:47-56): y = x * sigmoid(W2 swish(W1 mean_hw(x) + b1) + b2), per image and channel.
- *      x, y: bf16 NHWC views of c channels (y may be x); w1: f32 [squeeze][c], b1 f32 [squeeze], w2: f32 [c][squeeze],
- *      b2 f32 [c]; workspace: yolo_se_workspace_bytes(n, c) bytes (pooled means + scales, fp32). */
+ *      x, y: bf16 NHWC views of c channels (y may be x); w1: f32 [squeeze][c] (= _se_reduce.weight), b1 f32 [squeeze],
+ *      w2: f32 [squeeze][c] (= _se_expand.weight TRANSPOSED: lanes read consecutive channels), b2 f32 [c];
+ *      workspace: yolo_se_workspace_bytes(n, c) bytes (pooled means, scales and the pooling pass's partial sums, fp32;
+ *      the means stay in its first n*c floats). */
 YOLO_API size_t yolo_se_workspace_bytes(int n, int c);
 YOLO_API int yolo_se_fwd(const void* x, void* y, int n, int h, int w, int c, int in_c_total, int in_c_offset, int out_c_total,
                          int out_c_offset, const float* w1, const float* b1, const float* w2, const float* b2, int squeeze,

@@ -63,19 +63,25 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ 
 }
 
 // ---- squeeze-and-excitation ---------------------------------------------------------------------------------------------
-// (1) per (image, 8-channel chunk): mean over the h*w pixels.  Block = 256 threads: thread = (pixel stripe t / cgb, chunk t % cgb)
-// of a group of cgb <= 32 chunks; partial sums meet in LDS.
-__global__ __launch_bounds__(256) void se_mean_kernel(const bf16_t* __restrict__ x, float* __restrict__ mean, int hw, int c, int in_ct,
-                                                      int in_co, int cgb) {
+constexpr int kSeMaxSplits = 32;   // pixel ranges a map is cut into for the pooling pass (partial sums, added in a fixed order)
+
+// (1) per (image, group of <= 32 8-channel chunks, pixel range): partial sums over the range.  Block = 256 threads:
+//     thread = (pixel stripe t / cgb, chunk t % cgb); the stripes meet in LDS in a fixed order.
+__global__ __launch_bounds__(256) void se_partial_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial, int hw, int c,
+                                                         int in_ct, int in_co, int cgb, int splits) {
   __shared__ float part[256][8];
   const int cg = c >> 3;
   const int groups = (cg + cgb - 1) / cgb;
-  const int b = blockIdx.x / groups, grp = blockIdx.x % groups;
+  int bid = blockIdx.x;
+  const int sp = bid % splits;
+  bid /= splits;
+  const int b = bid / groups, grp = bid % groups;
   const int lc = threadIdx.x % cgb, stripe = threadIdx.x / cgb, nstripes = 256 / cgb;
   const int g = grp * cgb + lc;
+  const int per = (hw + splits - 1) / splits, p_lo = sp * per, p_hi = min(hw, p_lo + per);
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (g < cg && stripe < nstripes)
-    for (int p = stripe; p < hw; p += nstripes) {
+  if (g < cg)
+    for (int p = p_lo + stripe; p < p_hi; p += nstripes) {
       const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + ((long)b * hw + p) * in_ct + in_co + g * 8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
@@ -89,19 +95,25 @@ __global__ __launch_bounds__(256) void se_mean_kernel(const bf16_t* __restrict__
 #pragma unroll
       for (int e = 0; e < 8; ++e) tot[e] += part[st * cgb + lc][e];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) mean[(long)b * c + g * 8 + e] = tot[e] / (float)hw;
+    for (int e = 0; e < 8; ++e) partial[((long)b * splits + sp) * c + g * 8 + e] = tot[e];
   }
 }
 
-// (2) per image: hidden = swish(W1 mean + b1) (sq values), scale = sigmoid(W2 hidden + b2) (c values).
-//     W1: f32 [sq][c], W2: f32 [c][sq]; sq <= 64.
-__global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ mean, const float* __restrict__ w1,
-                                                    const float* __restrict__ b1, const float* __restrict__ w2,
-                                                    const float* __restrict__ b2, float* __restrict__ scale, int c, int sq) {
+// (2) per image: mean = sum of the partials / hw; hidden = swish(W1 mean + b1) (sq values); scale = sigmoid(W2 hidden + b2).
+//     W1: f32 [sq][c], W2T: f32 [sq][c] (the expand weight transposed: lanes read consecutive channels); sq <= 64.
+__global__ __launch_bounds__(1024) void se_fc_kernel(const float* __restrict__ partial, float* __restrict__ mean, const float* __restrict__ w1,
+                                                     const float* __restrict__ b1, const float* __restrict__ w2t, const float* __restrict__ b2,
+                                                     float* __restrict__ scale, int c, int sq, int splits, float inv_hw) {
   __shared__ float hid[64];
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float* m = mean + (long)b * c;
-  for (int j = wave; j < sq; j += 4) {               // one wave per hidden unit: lanes stride the channels
+  float* const m = mean + (long)b * c;
+  for (int i = threadIdx.x; i < c; i += 1024) {
+    float t = 0.f;
+    for (int sp = 0; sp < splits; ++sp) t += partial[((long)b * splits + sp) * c + i];
+    m[i] = t * inv_hw;
+  }
+  __syncthreads();
+  for (int j = wave; j < sq; j += 16) {              // one wave per hidden unit: lanes stride the channels
     float s = 0.f;
     for (int i = lane; i < c; i += 64) s = fmaf(w1[(long)j * c + i], m[i], s);
 #pragma unroll
@@ -112,9 +124,9 @@ __global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ me
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < c; i += 256) {
+  for (int i = threadIdx.x; i < c; i += 1024) {
     float s = b2[i];
-    for (int j = 0; j < sq; ++j) s = fmaf(w2[(long)i * sq + j], hid[j], s);
+    for (int j = 0; j < sq; ++j) s = fmaf(w2t[(long)j * c + i], hid[j], s);
     scale[(long)b * c + i] = 1.f / (1.f + expf(-s));
   }
 }
@@ -161,7 +173,7 @@ extern "C" int yolo_dwconv_fwd(const void* x, const float* w, const float* bias,
   return yolo_check_launch("yolo_dwconv_fwd");
 }
 
-extern "C" size_t yolo_se_workspace_bytes(int n, int c) { return (size_t)n * c * 2 * sizeof(float); }
+extern "C" size_t yolo_se_workspace_bytes(int n, int c) { return (size_t)n * c * (2 + kSeMaxSplits) * sizeof(float); }
 
 extern "C" int yolo_se_fwd(const void* x, void* y, int n, int h, int w_, int c, int in_c_total, int in_c_offset, int out_c_total,
                            int out_c_offset, const float* w1, const float* b1, const float* w2, const float* b2, int squeeze,
@@ -174,14 +186,19 @@ extern "C" int yolo_se_fwd(const void* x, void* y, int n, int h, int w_, int c, 
                "se: views must be 8-channel aligned");
   float* const mean = (float*)workspace;
   float* const scale = mean + (size_t)n * c;
+  float* const partial = scale + (size_t)n * c;
   const int hw = h * w_, cg = c / 8;
   const int cgb = cg < 32 ? (cg >= 16 ? 16 : cg >= 8 ? 8 : cg >= 4 ? 4 : cg >= 2 ? 2 : 1) : 32;    // power of two <= 32: 256 % cgb == 0
   const int groups = (cg + cgb - 1) / cgb;
-  hipLaunchKernelGGL(se_mean_kernel, dim3((unsigned)(n * groups)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, mean, hw, c,
-                     in_c_total, in_c_offset, cgb);
-  int rc = yolo_check_launch("yolo_se_fwd(mean)");
+  // enough workgroups for the chip: the 208x208 x 32-channel map of the first block is ONE channel group per image
+  int splits = 1;
+  while (splits < kSeMaxSplits && (long)n * groups * splits < 512 && hw / (splits * 2) >= 256) splits *= 2;
+  hipLaunchKernelGGL(se_partial_kernel, dim3((unsigned)(n * groups * splits)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, partial, hw,
+                     c, in_c_total, in_c_offset, cgb, splits);
+  int rc = yolo_check_launch("yolo_se_fwd(pool)");
   if (rc) return rc;
-  hipLaunchKernelGGL(se_fc_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)s, mean, w1, b1, w2, b2, scale, c, squeeze);
+  hipLaunchKernelGGL(se_fc_kernel, dim3((unsigned)n), dim3(1024), 0, (hipStream_t)s, partial, mean, w1, b1, w2, b2, scale, c, squeeze, splits,
+                     1.f / (float)hw);
   rc = yolo_check_launch("yolo_se_fwd(fc)");
   if (rc) return rc;
   const long total = (long)n * hw * cg;

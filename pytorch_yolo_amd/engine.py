@@ -679,7 +679,7 @@ class Plan:
                 x, y = nd.srcs[0], nd.outs[0]
                 sq = nd.attrs["w1"].shape[0]
                 w1 = self._dev(nd.attrs["w1"].detach().float().reshape(sq, x.c).contiguous())
-                w2 = self._dev(nd.attrs["w2"].detach().float().reshape(x.c, sq).contiguous())
+                w2 = self._dev(nd.attrs["w2"].detach().float().reshape(x.c, sq).t().contiguous())    # [sq][c]
                 b1, b2 = self._dev(nd.attrs["b1"].detach().float().contiguous()), self._dev(nd.attrs["b2"].detach().float().contiguous())
                 ws = self._dev(torch.zeros(K.se_workspace_bytes(x.n, x.c) // 4, dtype=torch.float32))
                 op = YoloOp()

@@ -195,7 +195,7 @@ def dwconv(x, wkc, bias, y, *, n, h, w, c, in_view, out_view, ho, wo, ksize, str
 
 
 def se(x, y, w1, b1, w2, b2, workspace, *, n, h, w, c, in_view, out_view):
-    """Squeeze-and-excitation (yolo_se_fwd): w1 f32 [sq][c], w2 f32 [c][sq]."""
+    """Squeeze-and-excitation (yolo_se_fwd): w1 f32 [sq][c], w2 f32 [sq][c] (the expand weight transposed)."""
     _need_cuda(x, y, w1, b1, w2, b2, workspace)
     check(load().yolo_se_fwd(_ptr(x), _ptr(y), n, h, w, c, in_view[0], in_view[1], out_view[0], out_view[1], _ptr(w1), _ptr(b1),
                              _ptr(w2), _ptr(b2), w1.shape[0], _ptr(workspace), workspace.numel() * workspace.element_size(),

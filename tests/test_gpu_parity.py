@@ -1685,7 +1685,7 @@ def test_squeeze_excite(n, h, w, c, sq):
     xin[..., 8:] = _nhwc(x)
     y = torch.full((n, h, w, c + 16), -77.0, dtype=torch.bfloat16, device=DEV)
     ws = torch.zeros(K.se_workspace_bytes(n, c) // 4, dtype=torch.float32, device=DEV)
-    K.se(xin, y, w1.to(DEV), b1.to(DEV), w2.to(DEV), b2.to(DEV), ws, n=n, h=h, w=w, c=c, in_view=(c + 8, 8), out_view=(c + 16, 16))
+    K.se(xin, y, w1.to(DEV), b1.to(DEV), w2.t().contiguous().to(DEV), b2.to(DEV), ws, n=n, h=h, w=w, c=c, in_view=(c + 8, 8), out_view=(c + 16, 16))
     xr = _bf16r(x)
     s_ = F.conv2d(swish(F.conv2d(F.adaptive_avg_pool2d(xr, 1), w1[:, :, None, None], b1)), w2[:, :, None, None], b2)
     ref = torch.sigmoid(s_) * xr
