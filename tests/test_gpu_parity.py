@@ -928,11 +928,13 @@ def test_model_full_size(name):
     assert (d2[0] is None) == (dets[0] is None) and (d2[0] is None or torch.equal(d2[0], dets[0]))
 
 
-@pytest.mark.parametrize("family,bs,h,w", [("spp", 2, 416, 416), ("spp", 1, 320, 512), ("tiny", 3, 320, 416), ("spp", 16, 160, 160)])
+@pytest.mark.parametrize("family,bs,h,w", [("spp", 2, 416, 416), ("spp", 1, 320, 512), ("tiny", 3, 320, 416), ("spp", 16, 160, 160),
+                                           ("spp", 2, 608, 608), ("spp", 1, 608, 320)])
 def test_full_width_models_at_other_input_sizes(family, bs, h, w):
     """Full-width models (kernels_divider 1, nc 80) at input sizes other than the BASELINE ones — other map sizes pick
     other tile configurations / fusions (e.g. 52x52 and 26x26 maps, rectangular inputs, the stem with partial tiles,
-    sub-batches of 8 on two streams) — against the fp32 oracle on the same seeded weights and images."""
+    sub-batches of 8 on two streams; 608: maps of 152 / 76 / 38 / 19 pixels, which the 20x20-tile kernel takes with partial
+    tiles on two edges) — against the fp32 oracle on the same seeded weights and images."""
     kw = dict(n_class=80, kernels_divider=1, anchors=C.SPP_ANCHORS if family == "spp" else C.TINY_ANCHORS)
     case = (family, kw, bs, h, w, 41, 42)
     model, sd, x = build_case(case)
