@@ -116,12 +116,17 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds
 // 32x32x16 fragment shapes.
 __device__ __forceinline__ int swz32(int v) { return (0x78 >> (2 * (v & 3))) & 3; }
 
+// act(v + bias) of the conv epilogues.  ONE data-independent formula covers none / LeakyReLU(0.1) / ReLU / ReLU6:
+// min(max(v, lo), hi) with lo = 0 or slope * v - the selects are wave-uniform and loop-invariant, so an unrolled epilogue pays
+// 4 VALU per value.  (As a chain of `if (act == ...) return ...` every one of a tile's 64-256 values carried its own tree of
+// scalar compares and branches: ~10 s_cbranch per value, more cycles than the MFMAs of a short-K layer.)  Same bits as the chain
+// for every input: the expressions per activation are the ones it evaluated.  swish (x * sigmoid(x)) keeps a uniform branch.
 __device__ __forceinline__ float apply_act(float v, int act) {
-  if (act == YOLO_ACT_LEAKY01) return fmaxf(v, 0.1f * v);   // == (v > 0 ? v : 0.1 v) for every input incl. -0, inf, NaN; one instruction less
-  if (act == YOLO_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
-  if (act == YOLO_ACT_RELU) return fmaxf(v, 0.f);
-  if (act == YOLO_ACT_SWISH) return v / (1.f + expf(-v));   // x * sigmoid(x)
-  return v;
+  if (act == YOLO_ACT_SWISH) return v / (1.f + expf(-v));
+  const bool floor0 = act == YOLO_ACT_RELU || act == YOLO_ACT_RELU6;
+  const float slope = act == YOLO_ACT_LEAKY01 ? 0.1f : 1.f;
+  const float hi = act == YOLO_ACT_RELU6 ? 6.f : __builtin_inff();
+  return fminf(fmaxf(v, floor0 ? 0.f : slope * v), hi);
 }
 
 template <int N>

@@ -718,9 +718,9 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
     if (rc != 1) return rc;
   }
   // short-K 1x1 layers on the large maps: weight-stationary streaming kernel (conv1x1_stream.hip).  YOLO_CONV_PP bit 1024: never,
-  // bit 2048: every layer it can compute.
+  // bit 2048: every layer it can compute, bit 4096: the 8-wave form for the long-K layers (512 -> 256, 1024 -> 512).
   if (epi && std_out && d.ksize == 1 && conv_variant_override < 0 && !(conv_pp_mask & 1024) && a.splits <= 1) {
-    const int rc = launch_stream1x1(a, conv_pp_mask & 2048 ? 1 : 0, s);
+    const int rc = launch_stream1x1(a, (conv_pp_mask & 2048 ? 1 : 0) | (conv_pp_mask & 4096 ? 2 : 0), s);
     if (rc != 1) return rc;
   }
   if (epi && std_out && !(conv_debug_flags & 32) && conv_variant_override < 0 && !(conv_pp_mask & 8)) {   // large 3x3/s1 maps: halo-staged kernel

@@ -1746,7 +1746,10 @@ def test_efficientnet_variant_vs_oracle(n, h, w):
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout,act", [(2, 80, 80, 256, 128, "leaky"), (1, 160, 160, 128, 64, "leaky"), (3, 37, 41, 128, 128, "none"),
-                                              (1, 20, 20, 256, 64, "relu6"), (2, 13, 13, 256, 128, "swish")])
+                                              (1, 20, 20, 256, 64, "relu6"), (2, 13, 13, 256, 128, "swish"),
+                                              # the 8-wave form (two pixel buffers, a workgroup per cout block): long-K layers
+                                              (32, 40, 40, 512, 256, "leaky"), (16, 20, 20, 1024, 512, "leaky"), (3, 13, 13, 512, 256, "none"),
+                                              (2, 20, 20, 1024, 128, "swish"), (1, 7, 9, 512, 512, "leaky")])
 def test_conv1x1_stream_kernel(n, h, w, cin, cout, act):
     """conv1x1_stream.hip (weights stationary in registers, persistent workgroups, whole-K pixel tiles by LDS-DMA) forced onto
     every layer it takes (YOLO_CONV_PP bit 2048): against fp32 torch on the same bf16-rounded operands, channel-offset views on
@@ -1769,7 +1772,7 @@ def test_conv1x1_stream_kernel(n, h, w, cin, cout, act):
     old = lib.yolo_set_tuning(2, 0)
     try:
         for arm in (1024, 2048):
-            lib.yolo_set_tuning(2, arm)
+            lib.yolo_set_tuning(2, arm | (4096 if arm == 2048 and cin >= 512 else 0))
             y = torch.full((n, h, w, cout + 8), -77.0, dtype=torch.bfloat16, device=DEV)
             K.conv2d(xin, wp.to(DEV), bp.to(DEV), y, d)
             torch.cuda.synchronize()
