@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_t20v2_kernel(const ConvArgs a)
   const int tiles_x = (d.w + kT20 - 1) / kT20, tiles_y = (d.h + kT20 - 1) / kT20;
   int b, y0, x0, n0;
   {
-    int swz = xcd_swizzle(blockIdx.x, gridDim.x);
+    int swz = a.blk_total ? xcd_swizzle(blockIdx.x + a.blk_off, a.blk_total) : xcd_swizzle(blockIdx.x, gridDim.x);
     n0 = (swz % a.n_tiles) * CT;
     swz /= a.n_tiles;
     x0 = (swz % tiles_x) * kT20;
@@ -614,6 +614,14 @@ int launch_t20v2(const ConvArgs& a, hipStream_t s) {
   b.n_tiles = a.d.cout / 128;
   const long grid = (long)a.d.n * ((a.d.h + kT20 - 1) / kT20) * ((a.d.w + kT20 - 1) / kT20) * b.n_tiles;
   if (grid > 0x7fffffffL) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv grid too large");
+  if (a.debug & 131072) {     // A/B: pieces of <= 256 workgroups, one after the other (one workgroup of this launch list per CU)
+    for (long off = 0; off < grid; off += 256) {
+      b.blk_off = (int)off;
+      b.blk_total = (int)grid;
+      hipLaunchKernelGGL(conv3x3_t20v2_kernel<3>, dim3((unsigned)(grid - off < 256 ? grid - off : 256)), dim3(256), 0, s, b);
+    }
+    return yolo_check_launch("yolo_conv2d_fwd(t20v2 pieces)");
+  }
   if (a.debug & 64) hipLaunchKernelGGL(conv3x3_t20v2_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, b);   // A/B: four pixel fragments in flight
   else hipLaunchKernelGGL(conv3x3_t20v2_kernel<3>, dim3((unsigned)grid), dim3(256), 0, s, b);
   return yolo_check_launch("yolo_conv2d_fwd(t20v2)");

@@ -48,6 +48,7 @@ struct ConvArgs {
   int splits;
   float* ws;
   int* cnt;
+  int blk_off, blk_total;   // a launch that covers work items [blk_off, blk_off + gridDim.x) of blk_total (0: the grid is the whole list)
   int debug;    // YOLO_CONV_DEBUG, tuning / ablation only (results are wrong with bits 1..8 set):
                 //   1 no pixel DMA   2 no weight DMA   4 no MFMA   8 no epilogue   16 no LDS-staged epilogue
                 //   32 no halo kernel   128 no 128x256 tiles   256 no loader waves   512 8-wave 256x256 tiles

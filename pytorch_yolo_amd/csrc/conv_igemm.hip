@@ -694,6 +694,7 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
   a.x_bytes = (uint32_t)x_bytes;
   a.w_bytes = (uint32_t)w_bytes;
   a.debug = conv_debug_flags;
+  a.blk_off = a.blk_total = 0;
   a.splits = g_splitk.splits;
   a.ws = g_splitk.ws;
   a.cnt = g_splitk.cnt;
@@ -838,6 +839,7 @@ static int conv1_nchw(const float* x_nchw, int cin_real, const void* w_packed, c
   a.x_bytes = 0;
   a.w_bytes = 0;
   a.debug = 0;
+  a.blk_off = a.blk_total = 0;
   a.splits = 1;
   a.ws = nullptr;
   a.cnt = nullptr;
