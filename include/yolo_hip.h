@@ -84,6 +84,10 @@ typedef struct YoloConvDesc {
 YOLO_API int yolo_conv2d_fwd(const void* x, const void* w_packed, const float* bias, const void* residual,
                     void* y, void* y_preadd, const YoloConvDesc* d, yolo_stream_t s);
 
+/* The kernel instance + grid yolo_conv2d_fwd would launch for d ("t20v2<...> grid 512"): nothing is launched and no GPU is
+ * needed - the regression guard of the tile rules (tests pin the BASELINE shapes). */
+YOLO_API int yolo_conv2d_pick(const YoloConvDesc* d, int has_residual, int has_preadd, char* out, int out_len);
+
 /* Split-K form for layers with few pixels and a long K (3x3 256 -> 512 on 13x13, 3x3 1280 -> 64 on 13x13: fewer tiles than
  * half the CUs): `splits` workgroups share a tile's K range, write fp32 partials to `workspace` and the last one to
  * arrive (counters, zero-initialised once by the caller, self-resetting) sums them in split order and runs the normal

@@ -60,6 +60,7 @@ SIGNATURES = {
                                           C.POINTER(YoloConvDesc), C.c_void_p]),
     "yolo_conv1_pool_nchw_f32_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.POINTER(YoloConvDesc), C.c_void_p]),
+    "yolo_conv2d_pick": (C.c_int, [C.POINTER(YoloConvDesc), C.c_int, C.c_int, C.c_char_p, C.c_int]),
     "yolo_pack_conv_weight_f32": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
     "yolo_stem_supported": (C.c_int, [C.c_int] * 5),
     "yolo_stem_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

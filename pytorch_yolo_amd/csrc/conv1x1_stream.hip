@@ -239,6 +239,7 @@ int launch_stream8(const ConvArgs& a, hipStream_t s) {
   const int px_tiles = (a.M + P - 1) / P, cbs = a.d.cout / NB;
   int grid = 256 / cbs * cbs;                         // one persistent workgroup per CU, a multiple of the cout blocks
   if (grid > px_tiles * cbs) grid = px_tiles * cbs;
+  if (pick_only("stream1x1_8waves<%d couts,K %d,%d px> grid %d", NB, K, P, grid)) return 0;
   hipLaunchKernelGGL((conv1x1_stream8_kernel<NB, K, P>), dim3((unsigned)grid), dim3(512), 0, s, a, px_tiles, cbs);
   return yolo_check_launch("yolo_conv2d_fwd(1x1 stream8)");
 }
@@ -247,6 +248,7 @@ template <int N, int K>
 int launch_stream(const ConvArgs& a, hipStream_t s) {
   const int tiles = (a.M + 127) / 128;
   const int grid = tiles < 512 ? tiles : 512;        // two persistent workgroups per CU
+  if (pick_only("stream1x1<%d couts,K %d> grid %d", N, K, grid)) return 0;
   hipLaunchKernelGGL((conv1x1_stream_kernel<N, K>), dim3((unsigned)grid), dim3(256), 0, s, a, tiles);
   return yolo_check_launch("yolo_conv2d_fwd(1x1 stream)");
 }

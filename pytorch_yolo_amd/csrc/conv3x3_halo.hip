@@ -383,6 +383,7 @@ int launch(const ConvArgs& a, hipStream_t s) {
   b.n_tiles = (a.d.cout + BN - 1) / BN;
   const long grid = (long)a.d.n * ((a.d.h + TH - 1) / TH) * ((a.d.w + TW - 1) / TW) * b.n_tiles;
   if (grid > 0x7fffffffL) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv grid too large");
+  if (pick_only("halo<%dx%d,%d couts,CK%d,%d halo buffers%s> grid %ld", TH, TW, BN, CK, HB, M16 ? ",16x16x32" : "", grid)) return 0;
   hipLaunchKernelGGL((conv3x3_halo_kernel<TH, TW, BN, WAVES_M, WAVES_N, CK, HB, M16>), dim3((unsigned)grid),
                      dim3(64 * WAVES_M * WAVES_N), 0, s, b);
   return yolo_check_launch("yolo_conv2d_fwd(halo)");

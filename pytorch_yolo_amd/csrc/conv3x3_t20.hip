@@ -614,6 +614,7 @@ int launch_t20v2(const ConvArgs& a, hipStream_t s) {
   b.n_tiles = a.d.cout / 128;
   const long grid = (long)a.d.n * ((a.d.h + kT20 - 1) / kT20) * ((a.d.w + kT20 - 1) / kT20) * b.n_tiles;
   if (grid > 0x7fffffffL) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv grid too large");
+  if (pick_only("t20v2<400px x 128 couts, 4 waves> grid %ld", grid)) return 0;
   if (a.debug & 131072) {     // A/B: pieces of <= 256 workgroups, one after the other (one workgroup of this launch list per CU)
     for (long off = 0; off < grid; off += 256) {
       b.blk_off = (int)off;
@@ -633,6 +634,7 @@ int launch_t20(const ConvArgs& a, hipStream_t s) {
   b.n_tiles = a.d.cout / CT;
   const long grid = (long)a.d.n * ((a.d.h + kT20 - 1) / kT20) * ((a.d.w + kT20 - 1) / kT20) * b.n_tiles;
   if (grid > 0x7fffffffL) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv grid too large");
+  if (pick_only("t20<%d couts,%d pixel groups> grid %ld", CT, NWM, grid)) return 0;
   hipLaunchKernelGGL((conv3x3_t20_kernel<CT, NWM>), dim3((unsigned)grid), dim3(64 * (CT / 64) * NWM), 0, s, b);
   return yolo_check_launch("yolo_conv2d_fwd(t20)");
 }

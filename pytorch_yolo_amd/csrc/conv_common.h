@@ -295,6 +295,11 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nblk) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// yolo_conv2d_pick (the tile-rule regression guard): while pick_buffer() is non-null the launch functions write the name of the
+// kernel instance they would launch there and return 0 WITHOUT launching (no GPU needed).
+char* pick_buffer();
+bool pick_only(const char* fmt, ...);   // true (and the name recorded) in pick mode
+
 int launch_halo3x3(const ConvArgs& a, hipStream_t s);   // conv3x3_halo.hip; returns 1 if it does not apply
 int launch_t20_3x3(const ConvArgs& a, int force, hipStream_t s);   // conv3x3_t20.hip (20x20 output tiles); 1 if it does not apply
 int launch_stream1x1(const ConvArgs& a, int force, hipStream_t s);   // conv1x1_stream.hip (weight-stationary 1x1 on large maps); 1 if it does not apply

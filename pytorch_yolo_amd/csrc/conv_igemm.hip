@@ -581,6 +581,9 @@ int launch_cfg(const ConvArgs& a, hipStream_t s) {
   b.steps = (a.d.ksize * a.d.ksize * a.d.cin + BK - 1) / BK;   // kpad >= steps*BK: the K tail is zero-padded
   const long grid = (long)m_tiles * b.n_tiles;
   if (grid > 0x7fffffffL) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv grid too large");
+  if (pick_only("igemm<%dx%d,%dx%d waves%s,BK%d,%d stages%s%s%s%s> grid %ld", BM, BN, WAVES_M, WAVES_N, NP ? "+4 loaders" : "", BK, NS,
+                FAST ? "" : ",generic", MFMA16 ? ",16x16x32" : ",32x32x16", DECODE ? ",decode" : "", SPLITK ? ",splitK" : "", grid))
+    return 0;
   unsigned gy = 1;
   if constexpr (SPLITK) {
     YOLO_REQUIRE(a.splits >= 2 && b.steps % a.splits == 0 && a.ws && a.cnt, "split-K: %d K steps do not split %d ways", b.steps, a.splits);
@@ -592,6 +595,23 @@ int launch_cfg(const ConvArgs& a, hipStream_t s) {
   return yolo_check_launch("yolo_conv2d_fwd");
 }
 
+}  // namespace
+
+namespace yolo_conv {
+static thread_local char* g_pick = nullptr;
+static thread_local int g_pick_len = 0;
+char* pick_buffer() { return g_pick; }
+bool pick_only(const char* fmt, ...) {
+  if (!g_pick) return false;
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_pick, g_pick_len, fmt, ap);
+  va_end(ap);
+  return true;
+}
+}  // namespace yolo_conv
+
+namespace {
 int conv_variant_override = -1;
 int conv_debug_flags = 0;   // tuning hook (YOLO_CONV_VARIANT), see yolo_conv2d_launch
 int conv_pp_mask = 0;       // YOLO_CONV_PP: which tile rules hand their layers to the ping-pong kernel (conv_pp.hip)
@@ -858,6 +878,20 @@ extern "C" int yolo_conv1_nchw_f32_fwd(const float* x_nchw, int cin_real, const 
 extern "C" int yolo_conv1_pool_nchw_f32_fwd(const float* x_nchw, int cin_real, const void* w_packed, const float* bias,
                                             void* y_pooled, const YoloConvDesc* dp, yolo_stream_t s) {
   return conv1_nchw(x_nchw, cin_real, w_packed, bias, y_pooled, dp, true, s);
+}
+
+// Which kernel instance and grid yolo_conv2d_fwd would launch for this layer (no launch, no GPU): the regression guard of the
+// tile rules (tests/test_host_cpu.py pins the BASELINE shapes).
+extern "C" int yolo_conv2d_pick(const YoloConvDesc* d, int has_residual, int has_preadd, char* out, int out_len) {
+  YOLO_REQUIRE(d && out && out_len > 0, "conv2d_pick: bad arguments");
+  out[0] = 0;
+  yolo_conv::g_pick = out;
+  yolo_conv::g_pick_len = out_len;
+  static const char dummy[16] = {0};
+  const int rc = yolo_conv2d_launch(dummy, dummy, (const float*)dummy, has_residual ? dummy : nullptr, (void*)dummy,
+                                    has_preadd ? (void*)dummy : nullptr, d, nullptr);
+  yolo_conv::g_pick = nullptr;
+  return rc;
 }
 
 extern "C" int yolo_conv2d_fwd(const void* x, const void* w_packed, const float* bias, const void* residual, void* y,

@@ -209,6 +209,7 @@ int launch_pp_cfg(const ConvArgs& a, hipStream_t s) {
   b.steps = a.d.ksize * a.d.ksize * a.d.cin / 32;
   const long grid = (long)((a.M + BM - 1) / BM) * b.n_tiles;
   if (grid > 0x7fffffffL) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv grid too large");
+  if (pick_only("pingpong<%dx%d> grid %ld", BM, BN, grid)) return 0;
   hipLaunchKernelGGL((conv_pp_kernel<BM, BN>), dim3((unsigned)grid), dim3(512), 0, s, b);
   return yolo_check_launch("yolo_conv2d_fwd(pp)");
 }

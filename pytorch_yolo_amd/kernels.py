@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU6, DT_BF16, DT_F32, YoloConvDesc, YoloMbconvDesc,
                    check, load)
 
-__all__ = ["stream_ptr", "pack_input", "conv2d", "stem", "resunit", "resunit_supported", "maxpool", "spp", "dwconv3x3", "dwconv", "se", "se_workspace_bytes", "mbconv", "mbconv_supported", "pack_mbconv", "conv3x3_pool", "conv3x3_pool_supported", "conv2d_splitk", "conv2d_splitk_plan", "decode", "head_decode", "head_decode_supported",
+__all__ = ["stream_ptr", "pack_input", "conv2d", "conv2d_pick", "stem", "resunit", "resunit_supported", "maxpool", "spp", "dwconv3x3", "dwconv", "se", "se_workspace_bytes", "mbconv", "mbconv_supported", "pack_mbconv", "conv3x3_pool", "conv3x3_pool_supported", "conv2d_splitk", "conv2d_splitk_plan", "decode", "head_decode", "head_decode_supported",
            "nms_merge", "pack_conv_weight", "roundup", "run_ops"]
 
 
@@ -121,6 +121,13 @@ def conv_desc(*, n, h, w, cin, in_c_total, in_c_offset, cout, out_c_total, out_c
     d.res_c_total, d.res_c_offset = res
     d.aux_c_total, d.aux_c_offset = aux
     return d
+
+
+def conv2d_pick(desc: YoloConvDesc, has_residual=False, has_preadd=False) -> str:
+    """Name + grid of the kernel instance yolo_conv2d_fwd would launch for ``desc`` (no launch, works without a GPU)."""
+    buf = C.create_string_buffer(256)
+    check(load().yolo_conv2d_pick(C.byref(desc), int(has_residual), int(has_preadd), buf, 256), "conv2d_pick")
+    return buf.value.decode()
 
 
 def conv2d(x, w_packed, bias, y, desc: YoloConvDesc, residual=None, y_preadd=None):

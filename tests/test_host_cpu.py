@@ -318,3 +318,47 @@ def test_efficientnet_mirror_structure_and_padding():
     x, w = torch.randn(1, 4, 8, 8), torch.randn(4, 1, 5, 5)
     ref = F.conv2d(F.pad(x, [1, 2, 1, 2]), w, stride=2, groups=4)           # 8 / k5 / s2: out 4, total pad 3 = 1 + 2
     assert torch.equal(conv_same(x, w, stride=2, groups=4), ref)
+
+
+def _pick(n, h, w, cin, cout, k, s, res=False):
+    kpad = ((k * k * cin + 63) // 64) * 64
+    cout_pad = ((cout + 127) // 128) * 128
+    d = K.conv_desc(n=n, h=h, w=w, cin=cin, in_c_total=cin, in_c_offset=0, cout=cout, out_c_total=cout, out_c_offset=0,
+                    ksize=k, stride=s, act=_lib.ACT_LEAKY01, kpad=kpad, cout_pad=cout_pad, res=(cout, 0) if res else (0, 0))
+    return K.conv2d_pick(d, res)
+
+
+def test_tile_rules_pick_the_intended_kernels():
+    """Regression guard for the selection rules (conv_igemm.hip::conv2d_launch_ex): yolo_conv2d_pick runs the
+    dispatcher without launching, so the kernel family each BASELINE SPP-640 layer (16-image sub-batch) lands on
+    is pinned here without a GPU.  A rule edit that silently moves a headline layer shows up as a diff."""
+    t20 = "t20v2<400px x 128 couts, 4 waves> grid %d"
+    expect = {
+        # 3x3 stride-1 residual convs of the four late Darknet stages: the 20x20-tile kernel, one block per (tile, 128 couts)
+        (16, 160, 160, 64, 128, 3, 1, True): t20 % 1024,
+        (16, 80, 80, 128, 256, 3, 1, True): t20 % 512,
+        (16, 40, 40, 256, 512, 3, 1, True): t20 % 256,
+        (16, 20, 20, 512, 1024, 3, 1, True): t20 % 128,
+        # stride-2 downsamples: implicit GEMM
+        (16, 160, 160, 128, 256, 3, 2): "igemm<256x256,4x4 waves,BK64,2 stages,16x16x32> grid 400",
+        (16, 80, 80, 256, 512, 3, 2): "igemm<256x256,4x4 waves,BK64,2 stages,16x16x32> grid 200",
+        (16, 40, 40, 512, 1024, 3, 2): "igemm<128x256,2x4 waves+4 loaders,BK64,3 stages,16x16x32> grid 200",
+        # memory-bound 1x1 bottlenecks at the two big maps: weight-stationary streaming kernel
+        (16, 80, 80, 256, 128, 1, 1): "stream1x1<128 couts,K 256> grid 512",
+        (16, 160, 160, 128, 64, 1, 1): "stream1x1<64 couts,K 128> grid 512",
+        # 1x1 at 40^2 / 20^2: implicit GEMM
+        (16, 40, 40, 512, 256, 1, 1): "igemm<128x256,2x8 waves,BK64,3 stages,16x16x32> grid 200",
+        (16, 20, 20, 1024, 512, 1, 1): "igemm<128x128,2x4 waves,BK64,3 stages,16x16x32> grid 200",
+        # too few tiles to fill the chip with 20x20 tiles: single-image 3x3 stays on the halo kernel
+        (1, 80, 80, 128, 256, 3, 1, True): "halo<16x16,128 couts,CK64,1 halo buffers,16x16x32> grid 50",
+    }
+    got = {k: _pick(*k) for k in expect}
+    assert got == expect
+    # 13x13 maps (416 input) do not tile by 20: never the t20 kernel
+    assert _pick(32, 13, 13, 512, 1024, 3, 1).startswith("igemm<")
+    # a bad descriptor is still rejected in pick mode
+    d = K.conv_desc(n=1, h=8, w=8, cin=32, in_c_total=32, in_c_offset=0, cout=32, out_c_total=32, out_c_offset=0,
+                    ksize=3, stride=1, act=_lib.ACT_LEAKY01, kpad=320, cout_pad=128)
+    d.cin = 0
+    with pytest.raises(Exception):
+        K.conv2d_pick(d)
