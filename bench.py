@@ -201,6 +201,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="spp", choices=list(WORKLOADS))
     ap.add_argument("--bs", type=int, default=0, help="images per GPU (default: the BASELINE config)")
+    ap.add_argument("--hw", type=int, default=0, help="square input size (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=2, help="concurrent sub-batch streams per GPU (1 = off)")
     ap.add_argument("--no-api", action="store_true", help="skip the API-level model.detect() timing")
@@ -243,7 +244,10 @@ def main():
         backend = dist.get_backend()
         assert dist.get_world_size() == args.gpus
 
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload])
+    if args.hw and args.hw != wl["hw"]:
+        wl["name"] = wl["name"].replace(f"{wl['hw']}x{wl['hw']}", f"{args.hw}x{args.hw}") + " (NOT the BASELINE input size)"
+        wl["hw"] = args.hw
     bs = args.bs or wl["bs"]
     model = wl["cls"](**wl["kw"]).eval()
     model.load_state_dict(synth_state_dict(model.state_dict(), 1234, n_class=80))
@@ -349,6 +353,8 @@ def main():
                "sharding": f"batch x{world}" + (" + RCCL all-gather of detections (side stream)" if sharded else ""),
                "mean_detections_per_image": round(sum(n_dets) / max(1, len(n_dets)), 1),
                "streams_per_gpu": n_streams, "precision": model.precision}
+        if n_streams > 1:
+            cfg["cu_partition"] = "half of every XCD per stream" if type(plan.streams[0]).__name__ == "ExternalStream" else "off (streams share the chip)"
         if sharded:
             cfg["rccl_ranks"], cfg["backend"] = dist.get_world_size(), backend
             try:

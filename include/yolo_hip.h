@@ -306,6 +306,12 @@ typedef struct YoloOp {
 } YoloOp;
 YOLO_API int yolo_run_ops(const YoloOp* ops, int n_ops, yolo_stream_t s);
 
+/* A HIP stream restricted to the compute units of cu_mask (bit i of the n_words x 32-bit vector = CU i; on MI355X CU i sits
+ * on XCD i % 8).  The host mirror runs the sub-batches of one detect() call on disjoint CU sets (engine.StreamedPlan);
+ * the reference has no counterpart (one torch stream, models/yolo_base.py forward).  Destroy with yolo_stream_destroy. */
+YOLO_API int yolo_stream_create_cu_mask(const uint32_t* cu_mask, int n_words, yolo_stream_t* out);
+YOLO_API int yolo_stream_destroy(yolo_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

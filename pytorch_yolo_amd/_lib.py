@@ -95,6 +95,8 @@ SIGNATURES = {
     "yolo_pack_input_nchw_f32_nhwc": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
     "yolo_pack_conv_weight_f32_f32": (C.c_int, [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
     "yolo_run_ops": (C.c_int, [C.POINTER(YoloOp), C.c_int, C.c_void_p]),
+    "yolo_stream_create_cu_mask": (C.c_int, [C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_void_p)]),
+    "yolo_stream_destroy": (C.c_int, [C.c_void_p]),
 }
 
 _lib = None

@@ -405,7 +405,9 @@ constexpr int kV2Pitch = 528;                        // fp32 staging row: 128 co
 constexpr int kV2Lds = 2 * kHaloB + kV2Hofs;
 static_assert(2 * 32 * kV2Pitch <= 2 * kHaloB, "epilogue buffers reuse the halo region");
 
-template <int XD>   // pixel fragments in flight: XD registers sets in rotation, XD - 1 patches ahead of the MFMAs
+// XD: pixel fragments in flight (XD register sets in rotation, XD - 1 patches ahead of the MFMAs); RD: residual rows in flight
+// in the epilogue (RD patch pairs ahead of the pair being stored)
+template <int XD, int RD>
 __global__ __launch_bounds__(256, 2) void conv3x3_t20v2_kernel(const ConvArgs a) {
   constexpr int CT = 128, NW = 4, NP = 25, HPT = 8;
   __shared__ __attribute__((aligned(16))) char smem[kV2Lds];
@@ -562,13 +564,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_t20v2_kernel(const ConvArgs a)
     return ok ? base + (uint32_t)(4 * pr * d.w + 4 * pc) * pitch : kOobOffset;
   };
   constexpr int NPAIR = (NP + 1) / 2;
-  u32x4 rv[2][2];
+  // The residual rows of pair pi are requested RD pairs before they are added, and nothing in the loop drains the vector-memory
+  // counter: the barrier is the raw one behind an LDS-only wait (a __syncthreads() would wait for every load and store in flight
+  // - one HBM round trip per pair, 13 in a row), the compiler's own counted vmcnt before the first use of a row does the rest.
+  u32x4 rv[RD + 1][2];
   auto fetch_res = [&](auto pc_) {
     constexpr int pi = decltype(pc_)::value, jp = 2 * pi;
 #pragma unroll
-    for (int u = 0; u < (jp + 1 < NP ? 2 : 1); ++u) rv[pi & 1][u] = __builtin_amdgcn_raw_buffer_load_b128(rr, voff(ro, r_pitch, jp + u), 0, 0);
+    for (int u = 0; u < (jp + 1 < NP ? 2 : 1); ++u)
+      rv[pi % (RD + 1)][u] = __builtin_amdgcn_raw_buffer_load_b128(rr, voff(ro, r_pitch, jp + u), 0, 0);
   };
-  if (a.res) fetch_res(std::integral_constant<int, 0>{});
+  if (a.res) static_for<RD>([&](auto kc) { fetch_res(kc); });
   static_for<NPAIR>([&](auto pc_) {
     constexpr int pi = decltype(pc_)::value, jp = 2 * pi;
     constexpr int NU = jp + 1 < NP ? 2 : 1;
@@ -580,10 +586,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_t20v2_kernel(const ConvArgs a)
         *reinterpret_cast<f32x4*>(slab + (u * 16 + c16) * kV2Pitch + (wave * 32 + i * 16 + q * 4) * 4) = act4(acc[i][jp + u] + bv[i]);
       });
     });
-    if constexpr (pi + 1 < NPAIR) {
-      if (a.res) fetch_res(std::integral_constant<int, pi + 1>{});
+    if constexpr (pi + RD < NPAIR) {
+      if (a.res) fetch_res(std::integral_constant<int, pi + RD>{});
     }
-    __syncthreads();                                    // the pair is staged by all four waves (and pair pi - 1 has been read by all)
+    wait_lds();
+    __builtin_amdgcn_s_barrier();                       // the pair is staged by all four waves (and pair pi - 1 has been read by all)
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       const int row = u * 16 + wave * 4 + lrow;
@@ -597,7 +604,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_t20v2_kernel(const ConvArgs a)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ra, voff(ao, x_pitch, jp + u), 0, 0);
       }
       if (a.res) {
-        const bf16x8 r8 = __builtin_bit_cast(bf16x8, rv[pi & 1][u]);
+        const bf16x8 r8 = __builtin_bit_cast(bf16x8, rv[pi % (RD + 1)][u]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
       }
@@ -619,12 +626,12 @@ int launch_t20v2(const ConvArgs& a, hipStream_t s) {
     for (long off = 0; off < grid; off += 256) {
       b.blk_off = (int)off;
       b.blk_total = (int)grid;
-      hipLaunchKernelGGL(conv3x3_t20v2_kernel<3>, dim3((unsigned)(grid - off < 256 ? grid - off : 256)), dim3(256), 0, s, b);
+      hipLaunchKernelGGL((conv3x3_t20v2_kernel<3, 3>), dim3((unsigned)(grid - off < 256 ? grid - off : 256)), dim3(256), 0, s, b);
     }
     return yolo_check_launch("yolo_conv2d_fwd(t20v2 pieces)");
   }
-  if (a.debug & 64) hipLaunchKernelGGL(conv3x3_t20v2_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, b);   // A/B: four pixel fragments in flight
-  else hipLaunchKernelGGL(conv3x3_t20v2_kernel<3>, dim3((unsigned)grid), dim3(256), 0, s, b);
+  if (a.debug & 64) hipLaunchKernelGGL((conv3x3_t20v2_kernel<3, 1>), dim3((unsigned)grid), dim3(256), 0, s, b);   // A/B: residual one pair ahead
+  else hipLaunchKernelGGL((conv3x3_t20v2_kernel<3, 3>), dim3((unsigned)grid), dim3(256), 0, s, b);
   return yolo_check_launch("yolo_conv2d_fwd(t20v2)");
 }
 

@@ -14,6 +14,26 @@ int yolo_set_error(int code, const char* fmt, ...) {
 extern "C" const char* yolo_last_error(void) { return g_err; }
 extern "C" int yolo_abi_version(void) { return 1; }
 
+// A stream whose kernels run only on the compute units named in cu_mask (bit i = CU i; on MI355X bit i lies on XCD i % 8).
+// engine.StreamedPlan gives each sub-batch stream its own half of every XCD so two layer lists really run side by side.
+extern "C" int yolo_stream_create_cu_mask(const uint32_t* cu_mask, int n_words, yolo_stream_t* out) {
+  YOLO_REQUIRE(cu_mask && out && n_words > 0 && n_words <= 64, "stream_create_cu_mask: bad arguments");
+  bool any = false;
+  for (int i = 0; i < n_words; ++i) any |= cu_mask[i] != 0;
+  YOLO_REQUIRE(any, "stream_create_cu_mask: empty mask");
+  hipStream_t st = nullptr;
+  hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, cu_mask);
+  if (e != hipSuccess) return yolo_set_error((int)e, "hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
+  *out = (yolo_stream_t)st;
+  return 0;
+}
+extern "C" int yolo_stream_destroy(yolo_stream_t s) {
+  YOLO_REQUIRE(s, "stream_destroy: null stream");
+  hipError_t e = hipStreamDestroy((hipStream_t)s);
+  if (e != hipSuccess) return yolo_set_error((int)e, "hipStreamDestroy: %s", hipGetErrorString(e));
+  return 0;
+}
+
 // One FFI crossing for a whole recorded layer list: the forward pass is ~80 launches, and at
 // ~3 us of Python/ctypes per call the host would otherwise be a visible fraction of a 5 ms batch.
 extern "C" int yolo_run_ops(const YoloOp* ops, int n_ops, yolo_stream_t s) {

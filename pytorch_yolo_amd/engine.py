@@ -935,25 +935,60 @@ class Plan:
         return self._static_out
 
 
+_masked_streams = {}
+
+
 class StreamedPlan:
     """The batch split into S contiguous sub-batches, each with its own Plan, run on S HIP streams.
 
     Images are independent, so results are identical; what changes is occupancy: the heavy layers launch
     200..800 tiles of 256x256 on 256 CUs, i.e. 1.56 or 3.1 "rounds", and the partial last round leaves a
     quarter of the chip idle.  Two kernels from two streams fill each other's tails (measured: -9.5 % on
-    the SPP-640 bs=32 layer list; four streams are no better than two)."""
+    the SPP-640 bs=32 layer list; four streams are no better than two).  Each stream owns half of every XCD's
+    compute units (_make_streams)."""
 
     def __init__(self, make_plan, bs: int, n_streams: int, device):
         assert bs % n_streams == 0
         self.sub = bs // n_streams
         self.subs = [make_plan(self.sub) for _ in range(n_streams)]
-        self.streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
+        self.streams = self._make_streams(n_streams, device, self.subs[0].conv_flops() / max(1, self.subs[0].n_ops))
         self._marks = [torch.cuda.Event() for _ in range(n_streams)]
         p0 = self.subs[0]
         self.device, self.n_class, self.img_size = device, p0.n_class, p0.img_size
         self.heads, self.rows_total = p0.heads, p0.rows_total
         self.bs = bs
         self._graph = None
+
+    @staticmethod
+    def _make_streams(n_streams, device, flops_per_launch=0.0):
+        """Each sub-batch stream owns its own compute units: stream i gets CUs [i, i+1) * per_xcd / S of every XCD (CU-mask bit b
+        lies on XCD b % 8), so two layer lists really run side by side - one stream's HBM-bound phases (1x1 layers, epilogues)
+        under the other's MFMA-dense ones - instead of time-slicing the workgroup slots of the whole chip (a 3x3 launch takes
+        every register of every CU it lands on).  It pays where the launches are MFMA-dense and about one round of workgroups
+        long - the chip then runs against its socket power limit and half the CUs hold a higher clock.
+        Measured images/s, split vs shared: SPP-640 bs=32 +2.6 %, bs=16 +1.5 %, bs=64 -0.7 %; SPP-416 bs=32 -9 %; tiny-416 -2.5 %,
+        MobileNetV2-tiny -4.6 % (small launches).  "auto" therefore splits between 16 and 48 GFLOP per launch of a sub-batch
+        (SPP-640 at 8..16 images per stream); whole XCDs per stream ("xcd") lose 1 %.
+        YOLO_CU_PARTITION = auto (default) | split | xcd | off."""
+        mode = os.environ.get("YOLO_CU_PARTITION", "auto")
+        if mode == "auto":
+            mode = "split" if 16e9 <= flops_per_launch < 48e9 else "off"
+        n_cu = torch.cuda.get_device_properties(device).multi_processor_count
+        n_xcd = 8
+        per = n_cu // n_xcd
+        if mode in ("off", "0", "") or n_streams < 2 or n_cu % n_xcd or per % n_streams:
+            return [torch.cuda.Stream(device=device) for _ in range(n_streams)]
+        if mode == "split":
+            sets = [[b for b in range(n_cu) if (b // n_xcd) * n_streams // per == i] for i in range(n_streams)]
+        elif mode == "xcd" and n_xcd % n_streams == 0:
+            sets = [[b for b in range(n_cu) if (b % n_xcd) * n_streams // n_xcd == i] for i in range(n_streams)]
+        else:
+            raise RuntimeError(f"YOLO_CU_PARTITION={mode!r}: expected off, split or xcd")
+        idx = torch.device(device).index
+        key = (torch.cuda.current_device() if idx is None else idx, n_streams, mode)
+        if key not in _masked_streams:                      # HIP streams with a CU mask are created once per device and shared by the plans
+            _masked_streams[key] = [K.cu_masked_stream(s, device) for s in sets]
+        return _masked_streams[key]
 
     def new_outputs(self):
         no = self.n_class + 5

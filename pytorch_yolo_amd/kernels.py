@@ -331,5 +331,21 @@ def nms_merge(pred, conf_thres, nms_thres, out_dets, out_idx, out_count, workspa
                                 stream_ptr()), "nms_merge")
 
 
+def cu_masked_stream(cu_bits, device):
+    """A torch stream (ExternalStream over hipExtStreamCreateWithCUMask) whose kernels run only on the listed CU
+    indices (CU i sits on XCD i % 8).  The HIP stream lives as long as the process: it is never destroyed behind torch."""
+    cu_bits = list(cu_bits)
+    if not cu_bits or min(cu_bits) < 0:
+        raise RuntimeError("cu_masked_stream: empty or negative CU list")
+    n_words = (max(cu_bits) + 32) // 32
+    words = (C.c_uint32 * n_words)()
+    for b in cu_bits:
+        words[b // 32] |= 1 << (b % 32)
+    out = C.c_void_p()
+    with torch.cuda.device(device):
+        check(load().yolo_stream_create_cu_mask(words, n_words, C.byref(out)), "stream_create_cu_mask")
+    return torch.cuda.ExternalStream(out.value, device=device)
+
+
 def run_ops(op_array, n_ops: int):
     check(load().yolo_run_ops(op_array, n_ops, stream_ptr()), "run_ops")

@@ -1786,3 +1786,37 @@ def test_conv1x1_stream_kernel(n, h, w, cin, cout, act):
     assert torch.all(y[..., :8] == -77.0)
     diff = (y.float() - outs[1024].float()).abs()
     assert float(diff.max()) <= 2 ** -6 * max(1.0, float(y.float().abs().max()))
+
+
+def test_cu_masked_streams():
+    """yolo_stream_create_cu_mask: a conv launched on a stream that owns half of every XCD's CUs gives the bits of the unmasked
+    launch (work -> workgroup mapping never depends on where a workgroup lands), and the BASELINE plan (SPP-640, 16 images per
+    stream) gets such streams by default while the small-launch models keep ordinary ones."""
+    from pytorch_yolo_amd import kernels as K
+    from pytorch_yolo_amd import engine
+    from pytorch_yolo_amd._lib import ACT_LEAKY01
+    g = torch.Generator().manual_seed(5)
+    cin, cout, n, h, w = 128, 256, 2, 40, 40
+    x = torch.randn(n, h, w, cin, generator=g).to(torch.bfloat16).to(DEV)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    wp, bp, kpad, cout_pad = K.pack_conv_weight(wt, torch.randn(cout, generator=g) * 0.1, cin)
+    wp, bp = wp.to(DEV), bp.to(DEV)
+    d = K.conv_desc(n=n, h=h, w=w, cin=cin, in_c_total=cin, in_c_offset=0, cout=cout, out_c_total=cout, out_c_offset=0,
+                    ksize=3, stride=1, act=ACT_LEAKY01, kpad=kpad, cout_pad=cout_pad)
+    y0 = torch.zeros(n, h, w, cout, dtype=torch.bfloat16, device=DEV)
+    y1 = torch.zeros_like(y0)
+    K.conv2d(x, wp, bp, y0, d)
+    n_cu = torch.cuda.get_device_properties(DEV).multi_processor_count
+    st = K.cu_masked_stream([b for b in range(n_cu) if (b // 8) % 2 == 1], DEV)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st):
+        K.conv2d(x, wp, bp, y1, d)
+    st.synchronize()
+    assert torch.equal(y0, y1) and float(y0.float().abs().max()) > 0
+    with pytest.raises(RuntimeError):
+        K.cu_masked_stream([], DEV)
+    a = engine.StreamedPlan._make_streams(2, DEV, 32e9)
+    b = engine.StreamedPlan._make_streams(2, DEV, 32e9)
+    assert [type(s).__name__ for s in a] == ["ExternalStream"] * 2 and a[0].cuda_stream != a[1].cuda_stream
+    assert [s.cuda_stream for s in a] == [s.cuda_stream for s in b]          # one pair per device, shared by the plans
+    assert all(type(s).__name__ == "Stream" for s in engine.StreamedPlan._make_streams(2, DEV, 5e9))

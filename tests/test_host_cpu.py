@@ -56,6 +56,11 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert rc == -1 and b"null pointer" in lib.yolo_last_error()
     assert lib.yolo_nms_workspace_bytes(32, 25200, 80) > 32 * 25200 * 8
     assert lib.yolo_nms_workspace_bytes(0, 1, 1) == 0
+    out = ctypes.c_void_p()
+    assert lib.yolo_stream_create_cu_mask(None, 8, ctypes.byref(out)) == -1
+    zeros = (ctypes.c_uint32 * 8)()
+    assert lib.yolo_stream_create_cu_mask(zeros, 8, ctypes.byref(out)) == -1 and b"empty mask" in lib.yolo_last_error()
+    assert lib.yolo_stream_destroy(None) == -1
 
 
 def test_c_weight_packer_matches_torch_packer():

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--workload", default="spp")
     ap.add_argument("--bs", type=int, default=0)
     ap.add_argument("--repeat", type=int, default=5)
+    ap.add_argument("--cu-mask", default="", help="'half': time the ops on a stream that owns half of every XCD's CUs (YOLO_CU_PARTITION=split)")
     args = ap.parse_args()
     wl = bench.WORKLOADS[args.workload]
     bs = args.bs or wl["bs"]
@@ -38,6 +39,10 @@ def main():
     model = model.to(dev)
     model.n_streams = 1
     x = synth_images(bs, wl["hw"], wl["hw"], 0).to(dev)
+    if args.cu_mask == "half":
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(K.cu_masked_stream([b for b in range(n_cu) if (b // 8) < n_cu // 16], dev))
     plan = model.plan_for(x)
     plan.feed(x)
     plan._bind_outputs(*plan.new_outputs())
