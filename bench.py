@@ -74,6 +74,42 @@ def host_cores() -> int:
     return max(1, min(n, 16))
 
 
+def power_sample(step_fn, seconds: float = 2.0):
+    """Socket power and shader clock while the timed workload keeps running (OUTSIDE the timed region): rocm-smi read about
+    twice a second with ~0.3 s of steps queued ahead of every read.  DESIGN.md 3.1k: the MFMA-dense layers run against the
+    socket power limit, which is what holds roofline.frac where it is.  None when rocm-smi is not there."""
+    import re
+    import shutil
+    import statistics
+    import subprocess
+    if shutil.which("rocm-smi") is None:
+        return None
+    watts, mhz = [], []
+    t0 = time.perf_counter()
+    i = 0
+    while time.perf_counter() - t0 < seconds:
+        t1 = time.perf_counter()
+        for _ in range(60):
+            step_fn(i)
+            i += 1
+        try:
+            txt = subprocess.run(["rocm-smi", "-d", str(torch.cuda.current_device()), "--showpower", "--showclocks"],
+                                 capture_output=True, text=True, timeout=10).stdout
+        except Exception:                                        # noqa: BLE001 (diagnostic only)
+            return None
+        torch.cuda.synchronize()
+        busy = time.perf_counter() - t1
+        pw = re.search(r"Power \(W\): ([\d.]+)", txt)
+        sc = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", txt)
+        if pw and sc:
+            watts.append(float(pw.group(1)))
+            mhz.append(int(sc.group(1)))
+    if not watts:
+        return None
+    return {"socket_w": round(statistics.median(watts), 1), "sclk_mhz": int(statistics.median(mhz)), "samples": len(watts),
+            "cap_w": 1400, "how": "rocm-smi --showpower --showclocks while extra steps run after the timed region"}
+
+
 def cpu_baseline(workload: str, seconds_budget: float = 20.0):
     """The oracle (CPU restatement of the reference path) timed on this box's host cores."""
     import numpy as np
@@ -293,6 +329,29 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # (measured BEFORE the free-running loop: that loop creates the CU-partitioned streams, blocking streams whose mere existence
+    # taxes every NULL-stream operation of a host-bound detect() loop - engine.StreamedPlan)
+    # API-level number beside the device-level one: model.detect() as a caller sees it (fresh output tensors every call, the
+    # count D2H copy and the list[Tensor | None] split inside the timed region, host-synchronous); sharded runs time
+    # detect_sharded (forward + NMS + all-gather + split on every rank)
+    api_ips = None
+    if not args.no_api:
+        from pytorch_yolo_amd.distributed import detect_sharded
+        k_api = max(3, min(args.steps, 20))
+        with torch.no_grad():
+            call = (lambda: detect_sharded(model, x, CONF_THRES, NMS_THRES)) if sharded else (lambda: model.detect(x, CONF_THRES, NMS_THRES))
+            call()
+            sync_all()
+            ta = time.perf_counter()
+            for _ in range(k_api):
+                res = call()
+            sync_all()
+            tb = torch.tensor([time.perf_counter() - ta], dtype=torch.float64, device=dev)
+        if sharded:
+            dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+        api_ips = round(bs * world * k_api / float(tb.item()), 2)
+        assert len(res) == bs * world
+
     with torch.no_grad():
         for i in range(args.warmup):
             step(i)
@@ -315,27 +374,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
 
-    # API-level number beside the device-level one: model.detect() as a caller sees it (fresh output tensors every call, the
-    # count D2H copy and the list[Tensor | None] split inside the timed region, host-synchronous); sharded runs time
-    # detect_sharded (forward + NMS + all-gather + split on every rank)
-    api_ips = None
-    if not args.no_api:
-        from pytorch_yolo_amd.distributed import detect_sharded
-        k_api = max(3, min(args.steps, 20))
-        with torch.no_grad():
-            call = (lambda: detect_sharded(model, x, CONF_THRES, NMS_THRES)) if sharded else (lambda: model.detect(x, CONF_THRES, NMS_THRES))
-            call()
-            sync_all()
-            ta = time.perf_counter()
-            for _ in range(k_api):
-                res = call()
-            sync_all()
-            tb = torch.tensor([time.perf_counter() - ta], dtype=torch.float64, device=dev)
-        if sharded:
-            dist.all_reduce(tb, op=dist.ReduceOp.MAX)
-        api_ips = round(bs * world * k_api / float(tb.item()), 2)
-        assert len(res) == bs * world
-
     traffic, traffic_src = None, None
     try:        # HBM bytes of the conv launch list per step: from committed rocprofv3 --pmc passes of this command, not live
         tj = json.load(open(os.path.join(ROOT, "profiles", "conv_traffic.json")))[args.workload]
@@ -354,7 +392,7 @@ def main():
                "mean_detections_per_image": round(sum(n_dets) / max(1, len(n_dets)), 1),
                "streams_per_gpu": n_streams, "precision": model.precision}
         if n_streams > 1:
-            cfg["cu_partition"] = "half of every XCD per stream" if type(plan.streams[0]).__name__ == "ExternalStream" else "off (streams share the chip)"
+            cfg["cu_partition"] = "half of every XCD per stream" if type(plan.pipe_streams[0]).__name__ == "ExternalStream" else "off (streams share the chip)"
         if sharded:
             cfg["rccl_ranks"], cfg["backend"] = dist.get_world_size(), backend
             try:
@@ -404,6 +442,12 @@ def main():
                 "label": top["label"], "launches_per_sub_batch": top["launches"], "avg_ms_solo": round(top["ms"] / top["launches"], 4),
                 "flops_per_launch": top["flops"] / top["launches"], "achieved": round(tf, 1), "frac": round(tf / PEAK_BF16_TFLOPS, 4),
                 "share_of_list_time": round(top["ms"] / sum(g["ms"] for g in tab), 3)}
+        if world == 1 and not args.no_api:
+            with torch.no_grad():
+                pw = power_sample(lambda i: step(args.warmup + i % args.steps))
+            sync_all()
+            if pw is not None:
+                out["roofline"]["power"] = pw
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)

@@ -896,11 +896,13 @@ class Plan:
                 total += 2.0 * m_in * d.cin * 2
         return total
 
-    def new_outputs(self):
+    def new_outputs(self, want_p: bool = True):
+        """io and the raw head tensors p.  ``want_p=False`` (detect(): NMS reads io only) leaves p out: the head kernels then
+        skip its store (0.87 GB per 32 SPP-640 images) - p is ``(None, ...)``."""
         n = self.rec.input.n
         no = self.n_class + 5
         io = torch.empty((n, self.rows_total, no), dtype=torch.float32, device=self.device)
-        ps = tuple(torch.empty((n, hd["na"], hd["sym"].h, hd["sym"].w, no), dtype=torch.float32, device=self.device)
+        ps = tuple(torch.empty((n, hd["na"], hd["sym"].h, hd["sym"].w, no), dtype=torch.float32, device=self.device) if want_p else None
                    for hd in self.heads)
         return io, ps
 
@@ -951,7 +953,14 @@ class StreamedPlan:
         assert bs % n_streams == 0
         self.sub = bs // n_streams
         self.subs = [make_plan(self.sub) for _ in range(n_streams)]
-        self.streams = self._make_streams(n_streams, device, self.subs[0].conv_flops() / max(1, self.subs[0].n_ops))
+        # joined calls (forward(), detect()): ordinary streams - both sub-batches start together and stay in step, layer for layer,
+        # so a CU partition has nothing complementary to overlap and only costs (-6 % on detect()).  Free-running pipelines
+        # (launch_detect(join=False): bench.py, a serving loop) drift apart: there each stream owns half of every XCD.
+        # The partitioned streams are created on the first pipelined call only: they are BLOCKING streams
+        # (hipExtStreamCreateWithCUMask takes no flags), and while any exists every operation on the NULL stream - torch's default
+        # current stream - pays for the implicit synchronisation with them (host-bound detect() loop: -5..9 %).
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
+        self._pipe_streams = None
         self._marks = [torch.cuda.Event() for _ in range(n_streams)]
         p0 = self.subs[0]
         self.device, self.n_class, self.img_size = device, p0.n_class, p0.img_size
@@ -990,10 +999,10 @@ class StreamedPlan:
             _masked_streams[key] = [K.cu_masked_stream(s, device) for s in sets]
         return _masked_streams[key]
 
-    def new_outputs(self):
+    def new_outputs(self, want_p: bool = True):
         no = self.n_class + 5
         io = torch.empty((self.bs, self.rows_total, no), dtype=torch.float32, device=self.device)
-        ps = tuple(torch.empty((self.bs, hd["na"], hd["sym"].h, hd["sym"].w, no), dtype=torch.float32, device=self.device)
+        ps = tuple(torch.empty((self.bs, hd["na"], hd["sym"].h, hd["sym"].w, no), dtype=torch.float32, device=self.device) if want_p else None
                    for hd in self.heads)
         return io, ps
 
@@ -1001,11 +1010,11 @@ class StreamedPlan:
         cur = torch.cuda.current_stream()
         if timing is not None:
             timing[0].record(cur)
+        self._fork(cur)
         for i, (pl, st) in enumerate(zip(self.subs, self.streams)):
             lo, hi = i * self.sub, (i + 1) * self.sub
-            st.wait_stream(cur)
             with torch.cuda.stream(st):
-                sub_ps = tuple(p[lo:hi] for p in ps)
+                sub_ps = tuple(None if p is None else p[lo:hi] for p in ps)
                 pl.feed(x[lo:hi])
                 pl._bind_outputs(io[lo:hi], sub_ps)
                 K.run_ops(pl.op_array, pl.n_ops)
@@ -1017,6 +1026,24 @@ class StreamedPlan:
             timing[1].record(cur)          # every stream's layer list is done (decodes may still run)
         for st in self.streams:
             cur.wait_stream(st)
+
+    @property
+    def pipe_streams(self):
+        if self._pipe_streams is None:
+            made = self._make_streams(len(self.streams), self.device, self.subs[0].conv_flops() / max(1, self.subs[0].n_ops))
+            # no partition: the SAME streams as the joined calls (more streams than hardware queues - 4 by default - end up sharing
+            # a queue, and two sub-batch pipelines on one queue run one after the other)
+            self._pipe_streams = made if type(made[0]).__name__ == "ExternalStream" else self.streams
+        return self._pipe_streams
+
+    def _fork(self, cur):
+        """Every sub-batch stream waits for the calling stream - ONE event, recorded before anything is launched.  The CU-masked
+        streams are blocking streams (hipExtStreamCreateWithCUMask takes no flags): an event recorded on the NULL stream between
+        the launches of two of them would wait for the first one's whole pass, and the sub-batches would run one after the other."""
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        for st in self.streams:
+            st.wait_event(ev)
 
     def run(self, x):
         io, ps = self.new_outputs()
@@ -1031,15 +1058,17 @@ class StreamedPlan:
         """Each stream runs the WHOLE pipeline (pack/conv1 -> layers -> decode -> NMS) of its sub-batch into
         slices of the shared buffers.  With ``join=False`` the calling stream neither waits for the previous
         work nor for this one: successive calls then form S free-running pipelines (in-order per stream, so
-        buffer reuse is safe) — the caller synchronises before reading results."""
+        buffer reuse is safe) — the caller synchronises before reading results, and before a joined call on the same plan
+        (the pipelines run on their own, CU-partitioned streams: ``pipe_streams``)."""
         from .utils.utils import nms_launch
         cur = torch.cuda.current_stream()
-        for i, (pl, st) in enumerate(zip(self.subs, self.streams)):
+        streams = self.streams if join else self.pipe_streams
+        if join:
+            self._fork(cur)
+        for i, (pl, st) in enumerate(zip(self.subs, streams)):
             lo, hi = i * self.sub, (i + 1) * self.sub
-            if join:
-                st.wait_stream(cur)
             with torch.cuda.stream(st):
-                pl._launch(x[lo:hi], io[lo:hi], tuple(p[lo:hi] for p in ps), timing=timing[i] if timing else None)
+                pl._launch(x[lo:hi], io[lo:hi], tuple(None if p is None else p[lo:hi] for p in ps), timing=timing[i] if timing else None)
                 nms_launch(io[lo:hi], conf_thres, nms_thres, tuple(t[lo:hi] for t in nms_out), slot=i)
                 if after_nms is not None:
                     after_nms(i, lo, hi)

@@ -240,7 +240,7 @@ class YOLOBase(nn.Module):
         x = x.float().contiguous()
         plan = self.plan_for(x)
         with torch.cuda.device(x.device):
-            io, ps = plan.new_outputs()
+            io, ps = plan.new_outputs(want_p=False)          # NMS reads io only: the raw head tensors are not materialised
             bs, cap = x.shape[0], nms_capacity(plan.rows_total, self.n_class)
             out = (torch.empty((bs, cap, 7), dtype=torch.float32, device=x.device),
                    torch.empty((bs, cap), dtype=torch.int32, device=x.device),

@@ -1820,3 +1820,29 @@ def test_cu_masked_streams():
     assert [type(s).__name__ for s in a] == ["ExternalStream"] * 2 and a[0].cuda_stream != a[1].cuda_stream
     assert [s.cuda_stream for s in a] == [s.cuda_stream for s in b]          # one pair per device, shared by the plans
     assert all(type(s).__name__ == "Stream" for s in engine.StreamedPlan._make_streams(2, DEV, 5e9))
+
+
+@pytest.mark.parametrize("name", ["spp_kd2_nc80", "tiny_small"])
+def test_detect_without_raw_head_tensors(name):
+    """detect() does not materialise p (engine.Plan.new_outputs(want_p=False)): io - and so the detections - are the bits of the
+    run that also stores p, for the head+decode epilogue (SPP) and the standalone decode kernel (narrow tiny heads) alike."""
+    from oracle import nms as onms
+    case = C.MODEL_CASES[name]
+    model, sd, x = build_case(case)
+    model = model.to(DEV)
+    xd = x.to(DEV)
+    with torch.no_grad():
+        io_ref, p_ref = model(xd)
+        plan = model.plan_for(xd)
+        io, ps = plan.new_outputs(want_p=False)
+        assert all(p is None for p in ps)
+        io.fill_(-1.0)
+        plan._launch(xd, io, ps)
+        torch.cuda.synchronize()
+        assert torch.equal(io, io_ref)
+        dets = model.detect(xd, conf_thres=0.05, nms_thres=0.5)
+    odets, _ = onms.non_max_suppression(io_ref.cpu().numpy().copy(), conf_thres=0.05, nms_thres=0.5)
+    for b in range(x.shape[0]):
+        assert (dets[b] is None) == (odets[b] is None)
+        if odets[b] is not None:
+            assert np.array_equal(dets[b].cpu().numpy(), odets[b])
