@@ -391,6 +391,7 @@ def main():
                "sharding": f"batch x{world}" + (" + RCCL all-gather of detections (side stream)" if sharded else ""),
                "mean_detections_per_image": round(sum(n_dets) / max(1, len(n_dets)), 1),
                "streams_per_gpu": n_streams, "precision": model.precision}
+        cfg["hip_hw_queues"] = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
         if n_streams > 1:
             cfg["cu_partition"] = "half of every XCD per stream" if type(plan.pipe_streams[0]).__name__ == "ExternalStream" else "off (streams share the chip)"
         if sharded:

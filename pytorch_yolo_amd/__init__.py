@@ -8,6 +8,15 @@
 Everything numeric runs in csrc/libyolo_hip.so (hand-written HIP for gfx950); there is no
 CPU or eager fallback.
 """
+import os as _os
+
+# HIP multiplexes its streams over GPU_MAX_HW_QUEUES hardware queues (4 by default).  One detect() pipeline per sub-batch, the
+# streams of the joined calls, the all-gather's side stream and RCCL's own make 6-7: on 4 queues two of them share one, and two
+# sub-batch pipelines on one queue run one after the other (measured: 5,740 -> 4,100 images/s in the sharded bench, -3 % in the
+# one-GPU one).  Read by the HIP runtime when it initialises, i.e. at the first torch.cuda call: import this package before that,
+# or export the variable yourself.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from .models import (LiteYOLOv3, YOLOv3, YOLOv3SPP, YOLOv3Tiny, YOLOv3TinyEfficient, YOLOv3TinyMobile, YOLOv3TinyShuffle,
                      YOLOv3TinySqueeze)
 from .utils.utils import non_max_suppression

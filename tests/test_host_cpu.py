@@ -228,6 +228,12 @@ def test_unsupported_widths_fail_loudly():
         YOLOv3Tiny(onnx=True, in_shape=(1, 3, 64, 64))
 
 
+def test_package_asks_for_enough_hardware_queues():
+    """pytorch_yolo_amd/__init__.py: GPU_MAX_HW_QUEUES defaults to 8 (two pipelines + joined-call streams + all-gather side
+    stream + RCCL's own do not fit HIP's default 4 queues: two sub-batch pipelines on one queue serialise)."""
+    assert int(os.environ["GPU_MAX_HW_QUEUES"]) >= 8
+
+
 def test_no_cpu_fallback():
     m = YOLOv3Tiny(kernels_divider=8, n_class=3).eval()
     with pytest.raises(RuntimeError, match="no CPU fallback"):
