@@ -798,14 +798,25 @@ class Plan:
         else:
             K.pack_input(x, self.input_buffer)
 
-    def _launch(self, x: torch.Tensor, io: torch.Tensor, ps, timing=None):
+    def _launch(self, x: torch.Tensor, io: torch.Tensor, ps, timing=None, before_io=None):
         """pack -> layer list -> decodes on the current stream.  ``timing`` = (start, end) torch events
-        recorded around the layer list (bench.py's roofline measurement)."""
+        recorded around the layer list (bench.py's roofline measurement).  ``before_io()`` is called right before the first
+        launch that writes ``io`` (a pipelined caller makes the stream wait there for the previous batch's NMS, which reads it)."""
         self.feed(x)
         self._bind_outputs(io, ps)
         if timing is not None:
             timing[0].record()
-        K.run_ops(self.op_array, self.n_ops)
+        fused = [hd["op"] for hd in self.heads if hd["op"] is not None]
+        k = min(fused) if fused else self.n_ops
+        if before_io is None or k == 0:
+            if before_io is not None:
+                before_io()
+            K.run_ops(self.op_array, self.n_ops)
+        else:
+            K.run_ops(self.op_array, k)
+            before_io()
+            if k < self.n_ops:
+                K.run_ops(C.cast(C.byref(self.op_array, k * C.sizeof(YoloOp)), C.POINTER(YoloOp)), self.n_ops - k)
         if timing is not None:
             timing[1].record()
         self._decode_unfused(io, ps)
@@ -961,6 +972,11 @@ class StreamedPlan:
         # current stream - pays for the implicit synchronisation with them (host-bound detect() loop: -5..9 %).
         self.streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
         self._pipe_streams = None
+        # pipelined calls: the NMS of a sub-batch runs on a stream of its own (all CUs), so the pipeline's stream goes straight on
+        # to the next batch's layer list; it waits for that NMS only in front of its first head launch (the next writer of io)
+        self._nms_stream = None
+        self._heads_done = [torch.cuda.Event() for _ in range(n_streams)]
+        self._nms_done = [None] * n_streams
         self._marks = [torch.cuda.Event() for _ in range(n_streams)]
         p0 = self.subs[0]
         self.device, self.n_class, self.img_size = device, p0.n_class, p0.img_size
@@ -1063,15 +1079,32 @@ class StreamedPlan:
         from .utils.utils import nms_launch
         cur = torch.cuda.current_stream()
         streams = self.streams if join else self.pipe_streams
+        side_nms = not join and os.environ.get("YOLO_NMS_STREAM", "1") != "0"
+        if side_nms and self._nms_stream is None:
+            self._nms_stream = torch.cuda.Stream(device=self.device)
         if join:
             self._fork(cur)
         for i, (pl, st) in enumerate(zip(self.subs, streams)):
             lo, hi = i * self.sub, (i + 1) * self.sub
+            sub_ps = tuple(None if p is None else p[lo:hi] for p in ps)
             with torch.cuda.stream(st):
-                pl._launch(x[lo:hi], io[lo:hi], tuple(None if p is None else p[lo:hi] for p in ps), timing=timing[i] if timing else None)
+                if not side_nms:
+                    pl._launch(x[lo:hi], io[lo:hi], sub_ps, timing=timing[i] if timing else None)
+                else:
+                    prev = self._nms_done[i]
+                    pl._launch(x[lo:hi], io[lo:hi], sub_ps, timing=timing[i] if timing else None,
+                               before_io=(lambda prev=prev, st=st: st.wait_event(prev)) if prev is not None else None)
+                    self._heads_done[i].record(st)
+            with torch.cuda.stream(self._nms_stream if side_nms else st):
+                if side_nms:
+                    self._nms_stream.wait_event(self._heads_done[i])
                 nms_launch(io[lo:hi], conf_thres, nms_thres, tuple(t[lo:hi] for t in nms_out), slot=i)
                 if after_nms is not None:
                     after_nms(i, lo, hi)
+                if side_nms:
+                    if self._nms_done[i] is None:
+                        self._nms_done[i] = torch.cuda.Event()
+                    self._nms_done[i].record(self._nms_stream)
         if join:
             for st in self.streams:
                 cur.wait_stream(st)

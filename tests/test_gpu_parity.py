@@ -1846,3 +1846,41 @@ def test_detect_without_raw_head_tensors(name):
         assert (dets[b] is None) == (odets[b] is None)
         if odets[b] is not None:
             assert np.array_equal(dets[b].cpu().numpy(), odets[b])
+
+
+def test_pipelined_detect_matches_joined_calls():
+    """launch_detect(join=False): sub-batch pipelines on their own streams, NMS on a side stream, io shared by successive batches
+    and no host sync in between - the detections of every batch equal those of joined calls (the pipeline's only cross-batch
+    hazard is io: the next batch's head launches wait for the previous batch's NMS)."""
+    from pytorch_yolo_amd.utils.synthetic import synth_images
+    from pytorch_yolo_amd.utils.utils import nms_capacity
+    case = C.MODEL_CASES["spp_kd2_nc80"]
+    model, sd, _ = build_case(case)
+    model = model.to(DEV)
+    model.n_streams = 2
+    bs = 8
+    xs = [synth_images(bs, 96, 64, 30 + k).to(DEV) for k in range(6)]
+    plan = model.plan_for(xs[0])
+    assert type(plan).__name__ == "StreamedPlan"
+    cap = nms_capacity(plan.rows_total, model.n_class)
+    mk = lambda: (torch.zeros((bs, cap, 7), device=DEV), torch.zeros((bs, cap), dtype=torch.int32, device=DEV),
+                  torch.zeros((bs,), dtype=torch.int32, device=DEV))
+    io, ps = plan.new_outputs(want_p=False)
+    with torch.no_grad():
+        want = []
+        for x in xs:
+            out = mk()
+            plan.launch_detect(x, io, ps, out, 0.02, 0.5, join=True)
+            torch.cuda.synchronize()
+            want.append(out)
+        got = [mk() for _ in xs]
+        for _ in range(3):                                   # the same six batches three times over: 18 back-to-back steps
+            for x, out in zip(xs, got):
+                plan.launch_detect(x, io, ps, out, 0.02, 0.5, join=False)
+        torch.cuda.synchronize()
+    assert plan._nms_stream is not None
+    assert sum(int(w[2].sum()) for w in want) > 0
+    for w, g in zip(want, got):
+        assert torch.equal(w[2], g[2])
+        for b, n in enumerate(w[2].tolist()):
+            assert torch.equal(w[0][b, :n], g[0][b, :n]) and torch.equal(w[1][b, :n], g[1][b, :n])
