@@ -300,7 +300,9 @@ def main():
     nms_out = (torch.empty((bs, cap, 7), dtype=torch.float32, device=dev),
                torch.empty((bs, cap), dtype=torch.int32, device=dev),
                torch.empty((bs,), dtype=torch.int32, device=dev))
-    io, ps = plan.new_outputs()
+    # detect() = non_max_suppression(model(x)[0], ...) (reference utils/utils.py:374-378): the raw head tensors p, which forward()
+    # also returns, are not part of it - the head kernels decode in their epilogue and skip the p store (as model.detect() does)
+    io, ps = plan.new_outputs(want_p=False)
     flops_step = plan.conv_flops()
 
     n_streams = plan.n_streams
@@ -391,6 +393,7 @@ def main():
                "sharding": f"batch x{world}" + (" + RCCL all-gather of detections (side stream)" if sharded else ""),
                "mean_detections_per_image": round(sum(n_dets) / max(1, len(n_dets)), 1),
                "streams_per_gpu": n_streams, "precision": model.precision}
+        cfg["raw_head_tensors_p"] = "not materialised: detect() discards them (forward() stores them; tests cover both)"
         cfg["hip_hw_queues"] = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
         if n_streams > 1:
             cfg["cu_partition"] = "half of every XCD per stream" if type(plan.pipe_streams[0]).__name__ == "ExternalStream" else "off (streams share the chip)"

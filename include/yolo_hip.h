@@ -311,6 +311,9 @@ YOLO_API int yolo_run_ops(const YoloOp* ops, int n_ops, yolo_stream_t s);
  * the reference has no counterpart (one torch stream, models/yolo_base.py forward).  Destroy with yolo_stream_destroy. */
 YOLO_API int yolo_stream_create_cu_mask(const uint32_t* cu_mask, int n_words, yolo_stream_t* out);
 YOLO_API int yolo_stream_destroy(yolo_stream_t s);
+/* Tell the tile rules how many compute units the coming launches of THIS thread may use (default 256; a CU-masked stream's share
+ * while launching on it): grids are sized against it.  Returns the previous value (<0: argument error). */
+YOLO_API int yolo_set_launch_cus(int n_cu);
 
 #ifdef __cplusplus
 }

@@ -97,6 +97,7 @@ SIGNATURES = {
     "yolo_run_ops": (C.c_int, [C.POINTER(YoloOp), C.c_int, C.c_void_p]),
     "yolo_stream_create_cu_mask": (C.c_int, [C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_void_p)]),
     "yolo_stream_destroy": (C.c_int, [C.c_void_p]),
+    "yolo_set_launch_cus": (C.c_int, [C.c_int]),
 }
 
 _lib = None

@@ -667,7 +667,7 @@ int yolo_conv::launch_t20_3x3(const ConvArgs& a, int force, hipStream_t s) {
     if ((double)d.n * d.h * d.w < 0.9 * 400.0 * tiles) return 1;          // partial tiles idle lanes
     // The second form is the shipped one: 400 pixels x 128 couts per workgroup, two workgroups per CU.  It needs enough workgroups
     // for half the chip (the other sub-batch stream's launch fills the rest): 16 images of the 20x20 maps give 128.
-    if (tiles * (d.cout / 128) < 128) return 1;
+    if (tiles * (d.cout / 128) < launch_cus() / 2) return 1;
     return launch_t20v2(a, s);
   }
   if (force & 4) return launch_t20v2(a, s);

@@ -623,6 +623,7 @@ struct SplitK {
   int* cnt = nullptr;
 };
 thread_local SplitK g_splitk;
+thread_local int g_launch_cus = 256;   // compute units the coming launches may use (a CU-masked stream: yolo_set_launch_cus)
 
 // The two shapes split-K serves (few pixels, long K, so few tiles that most CUs idle): tiles and K steps of the tile
 // configuration the dispatch below picks, or 0 tiles when the layer is not one of them.
@@ -655,6 +656,19 @@ static bool read_conv_env() {
     return true;
   }();
   return done;
+}
+
+namespace yolo_conv {
+int launch_cus() { return g_launch_cus; }
+}  // namespace yolo_conv
+
+// The tile rules below size grids against the compute units a launch can use: 256, or what the CU mask of the stream leaves
+// (engine.StreamedPlan gives each sub-batch pipeline half of every XCD).  Thread-local; returns the previous value.
+extern "C" int yolo_set_launch_cus(int n_cu) {
+  YOLO_REQUIRE(n_cu >= 8 && n_cu <= 1024, "set_launch_cus: %d out of range", n_cu);
+  const int old = g_launch_cus;
+  g_launch_cus = n_cu;
+  return old;
 }
 
 extern "C" int yolo_set_tuning(int knob, int value) {
@@ -755,7 +769,7 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
   // few pixels, few output channels, long K (MobileNetV2-tiny head: 3x3 1280 -> 64 on 13x13): 256-row tiles leave most
   // CUs idle, 64x64 tiles quadruple the workgroup count
   // ... and with one small workgroup per CU nothing hides the LDS-DMA latency of a two-stage ring: four stages
-  if (d.cout == 64 && fast64 && epi && (M + 255) / 256 < 128 && conv_variant_override < 0 && !(conv_debug_flags & 2048)) {
+  if (d.cout == 64 && fast64 && epi && (M + 255) / 256 < g_launch_cus / 2 && conv_variant_override < 0 && !(conv_debug_flags & 2048)) {
     if (a.splits > 1) return launch_cfg<64, 64, 2, 2, 64, 4, true, true, true, false, 0, true>(a, s);
     if (conv_debug_flags & 4194304) return launch_cfg<64, 64, 2, 2, 64, 2, true, true, true>(a, s);
     return launch_cfg<64, 64, 2, 2, 64, 4, true, true, true>(a, s);
@@ -766,16 +780,25 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
   // the 256 CUs; otherwise 128x128 (4 waves, two blocks per CU).  Measured on MI355X, see DESIGN.md.
   int pick = variant;
   if (conv_variant_override < 0) {
+    const int n_cu = g_launch_cus;
     const long tiles256 = ((M + 255) / 256) * (d.cout / 256);
-    pick = (d.cout % 256 == 0 && tiles256 >= 160) ? 5 : 0;
+    pick = (d.cout % 256 == 0 && tiles256 >= n_cu * 5 / 8) ? 5 : 0;
+    // ... unless 128x128 tiles (two workgroups per CU) fill their last round much better: on 128 CUs the stride-2 128 -> 256 layer
+    // is 400 tiles of 256x256 = 3.1 rounds (0.78) against 6.25 rounds of 128x128 (0.89): -8 %
+    if (pick == 5 && d.ksize == 3) {
+      const long t128 = ((M + 127) / 128) * (d.cout / 128);
+      const double e256 = (double)tiles256 / (double)(((tiles256 + n_cu - 1) / n_cu) * n_cu);
+      const double e128 = (double)t128 / (double)(((t128 + 2 * n_cu - 1) / (2 * n_cu)) * 2 * n_cu);
+      if (e128 > 1.1 * e256) pick = 0;
+    }
     // short-K 1x1 layers on big maps are latency/HBM-bound: 256x128 tiles with 32-deep stages keep
     // 16 waves per CU resident (two 8-wave blocks), which hides the per-tile prologue/epilogue
     if (d.ksize == 1 && d.cin <= 512 && M >= 40000) pick = 9;
     // 128x256 tiles (8 waves) when they cover the layer in one round of the 256 CUs: 25 % less operand traffic per
     // FLOP than 128x128 (-7 % on the 20x20 3x3 and the 40x40 1x1 layers)
-    if (pick == 0 && d.cout % 256 == 0 && ((M + 127) / 128) * (d.cout / 256) <= 256 && !(conv_debug_flags & 128)) pick = 12;
+    if (pick == 0 && d.cout % 256 == 0 && ((M + 127) / 128) * (d.cout / 256) <= n_cu && !(conv_debug_flags & 128)) pick = 12;
     // tiny grids (1x1 layers on the 20x20 maps): 64x64 tiles quadruple the block count so the chip fills
-    if (d.ksize == 1 && ((M + 127) / 128) * ((d.cout + 127) / 128) < 256) pick = 11;
+    if (d.ksize == 1 && ((M + 127) / 128) * ((d.cout + 127) / 128) < n_cu) pick = 11;
   }
   // 16x16x32 MFMA mainloop (same LDS traffic and cycles per FLOP as 32x32x16; the chip holds a higher clock on
   // it: +2..3 % measured on every shape).  YOLO_CONV_DEBUG bit 2048 falls back to 32x32x16.

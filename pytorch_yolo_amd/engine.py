@@ -951,6 +951,21 @@ class Plan:
 _masked_streams = {}
 
 
+class _launch_cus:
+    """with _launch_cus(n): the launches of this thread size their grids for n compute units (None: leave as is)."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __enter__(self):
+        self.old = K.set_launch_cus(self.n) if self.n else None
+
+    def __exit__(self, *exc):
+        if self.old is not None:
+            K.set_launch_cus(self.old)
+        return False
+
+
 class StreamedPlan:
     """The batch split into S contiguous sub-batches, each with its own Plan, run on S HIP streams.
 
@@ -1084,10 +1099,14 @@ class StreamedPlan:
             self._nms_stream = torch.cuda.Stream(device=self.device)
         if join:
             self._fork(cur)
+        # a partitioned pipeline launches on its share of the CUs: the tile rules size their grids against it
+        share = None
+        if not join and type(streams[0]).__name__ == "ExternalStream" and os.environ.get("YOLO_RULES_FOR_SHARE", "1") != "0":
+            share = torch.cuda.get_device_properties(self.device).multi_processor_count // len(streams)
         for i, (pl, st) in enumerate(zip(self.subs, streams)):
             lo, hi = i * self.sub, (i + 1) * self.sub
             sub_ps = tuple(None if p is None else p[lo:hi] for p in ps)
-            with torch.cuda.stream(st):
+            with torch.cuda.stream(st), _launch_cus(share):
                 if not side_nms:
                     pl._launch(x[lo:hi], io[lo:hi], sub_ps, timing=timing[i] if timing else None)
                 else:

@@ -347,5 +347,13 @@ def cu_masked_stream(cu_bits, device):
     return torch.cuda.ExternalStream(out.value, device=device)
 
 
+def set_launch_cus(n_cu: int) -> int:
+    """CUs the coming launches of this thread may use (tile rules size grids against it); returns the previous value."""
+    old = load().yolo_set_launch_cus(int(n_cu))
+    if old < 0:
+        check(old, "set_launch_cus")
+    return old
+
+
 def run_ops(op_array, n_ops: int):
     check(load().yolo_run_ops(op_array, n_ops, stream_ptr()), "run_ops")

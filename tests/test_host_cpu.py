@@ -373,3 +373,24 @@ def test_tile_rules_pick_the_intended_kernels():
     d.cin = 0
     with pytest.raises(Exception):
         K.conv2d_pick(d)
+
+
+def test_tile_rules_follow_the_cu_share_of_a_partitioned_stream():
+    """yolo_set_launch_cus: a pipelined sub-batch stream owns 128 of the 256 CUs and the rules size grids for that - the long-K
+    1x1 layers of the 20x20 maps leave the 3-stage 128x128 form for 128x256 tiles (100 workgroups = one round of 128 CUs), the
+    40x40 1x1 and the last stride-2 layer take 256x256 tiles (100 tiles), the stride-2 128->256 layer takes 128x128 tiles
+    (6.25 rounds at 0.89 instead of 3.1 at 0.78).  The 3x3 / stride-1 layers stay on the 20x20-tile kernel."""
+    old = K.set_launch_cus(128)
+    try:
+        assert K.set_launch_cus(128) == 128
+        assert _pick(16, 20, 20, 1024, 512, 1, 1) == "igemm<128x256,2x8 waves,BK64,3 stages,16x16x32> grid 100"
+        assert _pick(16, 40, 40, 512, 256, 1, 1) == "igemm<256x256,4x4 waves,BK64,2 stages,16x16x32> grid 100"
+        assert _pick(16, 40, 40, 512, 1024, 3, 2) == "igemm<256x256,4x4 waves,BK64,2 stages,16x16x32> grid 100"
+        assert _pick(16, 160, 160, 128, 256, 3, 2) == "igemm<128x128,2x4 waves,BK64,2 stages,16x16x32> grid 1600"
+        assert _pick(16, 20, 20, 512, 1024, 3, 1, True) == "t20v2<400px x 128 couts, 4 waves> grid 128"
+        assert _pick(16, 80, 80, 256, 128, 1, 1) == "stream1x1<128 couts,K 256> grid 512"
+    finally:
+        K.set_launch_cus(old)
+    assert _pick(16, 20, 20, 1024, 512, 1, 1) == "igemm<128x128,2x4 waves,BK64,3 stages,16x16x32> grid 200"
+    with pytest.raises(RuntimeError):
+        K.set_launch_cus(3)

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--workload", default="spp")
     ap.add_argument("--bs", type=int, default=0)
     ap.add_argument("--repeat", type=int, default=5)
+    ap.add_argument("--launch-cus", type=int, default=0, help="CU count the tile rules plan for (default: 256, or 128 under --cu-mask half)")
     ap.add_argument("--cu-mask", default="", help="'half': time the ops on a stream that owns half of every XCD's CUs (YOLO_CU_PARTITION=split)")
     args = ap.parse_args()
     wl = bench.WORKLOADS[args.workload]
@@ -43,6 +44,9 @@ def main():
         n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
         torch.cuda.synchronize()
         torch.cuda.set_stream(K.cu_masked_stream([b for b in range(n_cu) if (b // 8) < n_cu // 16], dev))
+        K.set_launch_cus(args.launch_cus or n_cu // 2)
+    elif args.launch_cus:
+        K.set_launch_cus(args.launch_cus)
     plan = model.plan_for(x)
     plan.feed(x)
     plan._bind_outputs(*plan.new_outputs())

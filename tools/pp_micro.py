@@ -23,8 +23,12 @@ DEFAULT = ["16,40,40,256,512,3,1,1", "16,20,20,512,1024,3,1,1", "16,80,80,128,25
 
 def main():
     args = sys.argv[1:]
-    rounds, reps, arms, knob = 5, 20, [0, 4], 2
+    rounds, reps, arms, knob, half = 5, 20, [0, 4], 2, False
     while args and args[0].startswith("--"):
+        if args[0] == "--half":                           # run on a stream that owns half of every XCD's CUs (a pipelined sub-batch stream)
+            half = True
+            args = args[1:]
+            continue
         if args[0] == "--rounds":
             rounds = int(args[1])
         elif args[0] == "--reps":
@@ -36,6 +40,10 @@ def main():
         args = args[2:]
     lib = load()
     dev = "cuda:0"
+    if half:
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(K.cu_masked_stream([b for b in range(n_cu) if (b // 8) < n_cu // 16], torch.device(dev)))
     for spec in args or DEFAULT:
         vals = [int(v) for v in spec.split(",")]
         n, h, w, cin, cout, k, stride = vals[:7]
