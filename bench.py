@@ -239,7 +239,10 @@ def main():
     ap.add_argument("--bs", type=int, default=0, help="images per GPU (default: the BASELINE config)")
     ap.add_argument("--hw", type=int, default=0, help="square input size (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=2, help="concurrent sub-batch streams per GPU (1 = off)")
+    ap.add_argument("--streams", type=int, default=2, help="concurrent pipelines per GPU (1 = off)")
+    ap.add_argument("--pipeline", default="batches", choices=["batches", "halves"],
+                    help="what a pipeline carries: whole batches, successive steps alternating between the pipelines (default), or "
+                         "one sub-batch of every step each")
     ap.add_argument("--no-api", action="store_true", help="skip the API-level model.detect() timing")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: rehearse the N-rank launcher and the all-gather over gloo, print a line with value null")
@@ -297,15 +300,21 @@ def main():
     plan = model.plan_for(x)
     rows, nc = plan.rows_total, model.n_class
     cap = nms_capacity(rows, nc)
-    nms_out = (torch.empty((bs, cap, 7), dtype=torch.float32, device=dev),
-               torch.empty((bs, cap), dtype=torch.int32, device=dev),
-               torch.empty((bs,), dtype=torch.int32, device=dev))
+    def new_nms_out():
+        return (torch.empty((bs, cap, 7), dtype=torch.float32, device=dev),
+                torch.empty((bs, cap), dtype=torch.int32, device=dev),
+                torch.empty((bs,), dtype=torch.int32, device=dev))
+    nms_out = new_nms_out()
     # detect() = non_max_suppression(model(x)[0], ...) (reference utils/utils.py:374-378): the raw head tensors p, which forward()
     # also returns, are not part of it - the head kernels decode in their epilogue and skip the p store (as model.detect() does)
     io, ps = plan.new_outputs(want_p=False)
     flops_step = plan.conv_flops()
 
     n_streams = plan.n_streams
+    # whole-batch pipelines: step i goes down pipeline i % S as ONE launch list of all its images, S batches in flight, each with
+    # its own output buffers (engine.StreamedPlan.launch_detect(whole_batch=True))
+    whole = args.pipeline == "batches" and n_streams > 1
+    sets = [(io, ps, nms_out)] + [(plan.new_outputs(want_p=False) + (new_nms_out(),)) for _ in range(n_streams - 1 if whole else 0)]
     total_steps = args.steps + args.warmup
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_streams)]
           for _ in range(total_steps)]
@@ -313,14 +322,18 @@ def main():
     # all-gather of every step rides a side stream (distributed.PipelinedGather) instead of joining them
     gatherer = PipelinedGather(bs, cap, n_streams, dev) if sharded else None
 
+    calls = [0]
+
     def step(i):
         """Per stream: conv1 (reads the NCHW batch) -> 75 conv launches + SPP -> 3 decodes -> NMS on its sub-batch
         (-> join + all-gather when sharded over ranks).  HIP events bracket every stream's conv launch list on
         the stream it is launched on."""
+        io, ps, nms_out = sets[calls[0] % len(sets)]         # call k goes down pipeline k % S: its buffer set
+        calls[0] += 1
         if gatherer is None:
-            plan.launch_detect(x, io, ps, nms_out, CONF_THRES, NMS_THRES, timing=ev[i], join=False)
+            plan.launch_detect(x, io, ps, nms_out, CONF_THRES, NMS_THRES, timing=ev[i], join=False, whole_batch=whole)
             return nms_out[0], nms_out[2]
-        plan.launch_detect(x, io, ps, nms_out, CONF_THRES, NMS_THRES, timing=ev[i], join=False,
+        plan.launch_detect(x, io, ps, nms_out, CONF_THRES, NMS_THRES, timing=ev[i], join=False, whole_batch=whole,
                            after_nms=gatherer.begin(nms_out))
         all_dets, all_count, _ = gatherer.exchange()
         return all_dets, all_count
@@ -368,7 +381,10 @@ def main():
     # pipelines drift against each other, so a union over streams would mix work of neighbouring steps)
     conv_ms = []
     for i in range(args.warmup, total_steps):
-        conv_ms.append(max(e0.elapsed_time(e1) for e0, e1 in ev[i]))
+        if whole:      # S whole-batch lists run side by side, each at 1/S of the chip's rate: a step's share of the chip's time
+            conv_ms.append(ev[i][0][0].elapsed_time(ev[i][0][1]) / n_streams)
+        else:
+            conv_ms.append(max(e0.elapsed_time(e1) for e0, e1 in ev[i]))
     n_dets = counts.cpu().tolist()
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -394,9 +410,13 @@ def main():
                "mean_detections_per_image": round(sum(n_dets) / max(1, len(n_dets)), 1),
                "streams_per_gpu": n_streams, "precision": model.precision}
         cfg["raw_head_tensors_p"] = "not materialised: detect() discards them (forward() stores them; tests cover both)"
+        if n_streams > 1:
+            cfg["pipelines"] = (f"{n_streams} x whole batches of {bs} (successive steps alternate)" if whole
+                                else f"{n_streams} x sub-batches of {bs // n_streams} of every step")
         cfg["hip_hw_queues"] = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
         if n_streams > 1:
-            cfg["cu_partition"] = "half of every XCD per stream" if type(plan.pipe_streams[0]).__name__ == "ExternalStream" else "off (streams share the chip)"
+            used = plan._full_streams if whole else plan.pipe_streams
+            cfg["cu_partition"] = "half of every XCD per stream" if type(used[0]).__name__ == "ExternalStream" else "off (streams share the chip)"
         if sharded:
             cfg["rccl_ranks"], cfg["backend"] = dist.get_world_size(), backend
             try:
@@ -423,7 +443,9 @@ def main():
             "config": cfg,
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "conv-family launch list of one forward (stem, resunit, conv3x3_t20v2, conv_igemm_bf16 incl. head+decode); per step the longest of the concurrent per-stream lists",
+                         "kernel": "conv-family launch list of one forward (stem, resunit, conv3x3_t20v2, conv_igemm_bf16 incl. head+decode); per step: "
+                                   + ("a whole-batch list's HIP-event time / the pipelines that run side by side" if whole
+                                      else "the longest of the concurrent per-stream lists"),
                          "flops_per_step": flops_step, "ms_per_step_conv": round(conv_ms_avg, 4)},
         }
         if args.workload != "spp":
@@ -439,11 +461,11 @@ def main():
         if world == 1:
             # the dominant kernel family by itself, live: every launch of one sub-batch list timed alone with HIP events
             with torch.no_grad():
-                tab = solo_kernel_table(plan.subs[0] if hasattr(plan, "subs") else plan)
+                tab = solo_kernel_table((plan._full[0] if whole else plan.subs[0]) if hasattr(plan, "subs") else plan)
             top = tab[0]
             tf = top["flops"] / (top["ms"] * 1e-3) / 1e12
             out["roofline"]["dominant_kernel"] = {
-                "label": top["label"], "launches_per_sub_batch": top["launches"], "avg_ms_solo": round(top["ms"] / top["launches"], 4),
+                "label": top["label"], "launches_per_list": top["launches"], "avg_ms_solo": round(top["ms"] / top["launches"], 4),
                 "flops_per_launch": top["flops"] / top["launches"], "achieved": round(tf, 1), "frac": round(tf / PEAK_BF16_TFLOPS, 4),
                 "share_of_list_time": round(top["ms"] / sum(g["ms"] for g in tab), 3)}
         if world == 1 and not args.no_api:

@@ -1870,17 +1870,41 @@ def test_pipelined_detect_matches_joined_calls():
         want = []
         for x in xs:
             out = mk()
-            plan.launch_detect(x, io, ps, out, 0.02, 0.5, join=True)
+            plan.launch_detect(x, io, ps, out, 1e-4, 0.5, join=True)
             torch.cuda.synchronize()
             want.append(out)
         got = [mk() for _ in xs]
         for _ in range(3):                                   # the same six batches three times over: 18 back-to-back steps
             for x, out in zip(xs, got):
-                plan.launch_detect(x, io, ps, out, 0.02, 0.5, join=False)
+                plan.launch_detect(x, io, ps, out, 1e-4, 0.5, join=False)
         torch.cuda.synchronize()
     assert plan._nms_stream is not None
     assert sum(int(w[2].sum()) for w in want) > 0
     for w, g in zip(want, got):
+        assert torch.equal(w[2], g[2])
+        for b, n in enumerate(w[2].tolist()):
+            assert torch.equal(w[0][b, :n], g[0][b, :n]) and torch.equal(w[1][b, :n], g[1][b, :n])
+    # whole batches alternating between the pipelines: two batches in flight, io alternates between two buffers.  Reference: the
+    # one-stream plan of the whole batch (the launch list a pipeline runs; the 4-image sub-batch lists above may pick other tiles)
+    model.n_streams = 1
+    plan1 = model.plan_for(xs[0])
+    assert type(plan1).__name__ == "Plan"
+    want = []
+    with torch.no_grad():
+        for x in xs:
+            out = mk()
+            plan1.launch_detect(x, io, ps, out, 1e-4, 0.5)
+            torch.cuda.synchronize()
+            want.append(out)
+    ios = [plan.new_outputs(want_p=False) for _ in range(2)]
+    got2 = [mk() for _ in xs]
+    with torch.no_grad():
+        for _ in range(3):
+            for k, (x, out) in enumerate(zip(xs, got2)):     # six batches per round: call k -> pipeline k % 2 -> buffer set k % 2
+                plan.launch_detect(x, ios[k % 2][0], ios[k % 2][1], out, 1e-4, 0.5, join=False, whole_batch=True)
+        torch.cuda.synchronize()
+    assert plan._full is not None and len(plan._full) == 2
+    for w, g in zip(want, got2):
         assert torch.equal(w[2], g[2])
         for b, n in enumerate(w[2].tolist()):
             assert torch.equal(w[0][b, :n], g[0][b, :n]) and torch.equal(w[1][b, :n], g[1][b, :n])
