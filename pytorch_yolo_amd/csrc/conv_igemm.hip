@@ -785,7 +785,8 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
     pick = (d.cout % 256 == 0 && tiles256 >= n_cu * 5 / 8) ? 5 : 0;
     // ... unless 128x128 tiles (two workgroups per CU) fill their last round much better: on 128 CUs the stride-2 128 -> 256 layer
     // is 400 tiles of 256x256 = 3.1 rounds (0.78) against 6.25 rounds of 128x128 (0.89): -8 %
-    if (pick == 5 && d.ksize == 3) {
+    // (measured on a 128-CU share only; on the whole chip the same round counts at 32 images favour the 256x256 tiles by 5 %)
+    if (pick == 5 && d.ksize == 3 && n_cu <= 128) {
       const long t128 = ((M + 127) / 128) * (d.cout / 128);
       const double e256 = (double)tiles256 / (double)(((tiles256 + n_cu - 1) / n_cu) * n_cu);
       const double e128 = (double)t128 / (double)(((t128 + 2 * n_cu - 1) / (2 * n_cu)) * 2 * n_cu);
