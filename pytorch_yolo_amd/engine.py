@@ -835,7 +835,8 @@ class Plan:
             if hd["op"] is None:
                 K.decode(hd["sym"].buf.tensor, hd["anchors"], self.n_class, hd["stride"], io, hd["row"], p)
 
-    def launch_detect(self, x, io, ps, nms_out, conf_thres, nms_thres, timing=None, join=True, after_nms=None, whole_batch=False):
+    def launch_detect(self, x, io, ps, nms_out, conf_thres, nms_thres, timing=None, join=True, after_nms=None, whole_batch=False,
+                      wait_for=None):
         """forward + decode + MERGE-NMS into caller-provided buffers; no host sync.
         nms_out = (dets [bs,cap,7] f32, idx [bs,cap] i32, count [bs] i32).  ``timing``: one (start, end)
         event pair per stream, recorded around the conv launch list.  ``after_nms(i, lo, hi)`` is called in
@@ -1086,8 +1087,12 @@ class StreamedPlan:
     def n_streams(self):
         return len(self.streams)
 
-    def launch_detect(self, x, io, ps, nms_out, conf_thres, nms_thres, timing=None, join=True, after_nms=None, whole_batch=False):
-        """``whole_batch=True`` (pipelined calls only): this call's WHOLE batch goes down ONE pipeline and successive calls
+    def launch_detect(self, x, io, ps, nms_out, conf_thres, nms_thres, timing=None, join=True, after_nms=None, whole_batch=False,
+                      wait_for=None):
+        """``wait_for``: an event every pipeline of this call waits for before its first launch (pipelined calls do not wait for
+        the calling stream: pass the event that says ``x`` is ready when another stream produced it).
+
+        ``whole_batch=True`` (pipelined calls only): this call's WHOLE batch goes down ONE pipeline and successive calls
         alternate between the pipelines - two batches in flight instead of two halves of one.  The launches are twice as large
         (SPP-640: 32 images instead of 16: +3.4 % images/s), a batch takes twice as long to come out, and the caller must hand
         consecutive calls DIFFERENT io / nms_out buffers (a buffer set may be reused every ``n_streams`` calls: the head launches
@@ -1128,6 +1133,8 @@ class StreamedPlan:
         for i, pl, st, lo, hi in work:
             sub_ps = tuple(None if p is None else p[lo:hi] for p in ps)
             tm = (timing[0 if whole else i] if timing else None)
+            if wait_for is not None:
+                st.wait_event(wait_for)
             with torch.cuda.stream(st), _launch_cus(share):
                 if not side_nms:
                     pl._launch(x[lo:hi], io[lo:hi], sub_ps, timing=tm)

@@ -231,6 +231,53 @@ class YOLOBase(nn.Module):
                 return plan.run_graph(x)
             return plan.run(x)
 
+    def detect_stream(self, batches, conf_thres=0.5, nms_thres=0.5):
+        """``detect()`` over a stream of equally shaped batches with the GPU kept busy: a generator that yields, in order, the
+        reference-style ``list[Tensor[n,7] | None]`` of every batch - batch k's list after batch k+S-1 has been launched (S = the
+        plan's pipelines, 2 by default).  Successive batches alternate between the pipelines (``launch_detect(whole_batch=True)``):
+        no host sync per batch except the count read-back of the batch being handed out, which by then has left the GPU.
+        SPP-640 x 32: ~6,000 images/s against ~4,700 for back-to-back ``detect()`` calls (bench.py)."""
+        from ..utils.utils import nms_capacity, split_detections
+        if self.training:
+            raise NotImplementedError("detect_stream() is an inference call: .eval() first")
+        ring, pending, plan, shape = [], [], None, None
+        for x in batches:
+            x = x.float().contiguous()
+            if shape is None:
+                shape = tuple(x.shape)
+                plan = self.plan_for(x)
+                depth = max(2, plan.n_streams)
+                cap = nms_capacity(plan.rows_total, self.n_class)
+                with torch.cuda.device(x.device):
+                    for _ in range(depth):
+                        io, ps = plan.new_outputs(want_p=False)
+                        out = (torch.empty((shape[0], cap, 7), dtype=torch.float32, device=x.device),
+                               torch.empty((shape[0], cap), dtype=torch.int32, device=x.device),
+                               torch.empty((shape[0],), dtype=torch.int32, device=x.device))
+                        ring.append((io, ps, out, torch.cuda.Event()))
+            elif tuple(x.shape) != shape:
+                raise RuntimeError(f"detect_stream: batch shape {tuple(x.shape)} differs from the first one {shape}")
+            while len(pending) >= len(ring):               # the oldest batch's buffers are needed again: hand it out first
+                yield self._collect(pending.pop(0))
+            k = self.__dict__.setdefault("_stream_calls", 0)
+            self._stream_calls = k + 1
+            io, ps, out, done = ring[k % len(ring)]
+            with torch.cuda.device(x.device):
+                ready = torch.cuda.Event()
+                ready.record()                               # x was produced on the caller's stream: the pipeline waits for it
+                plan.launch_detect(x, io, ps, out, conf_thres, nms_thres, join=False, whole_batch=True, wait_for=ready,
+                                   after_nms=lambda i, lo, hi, done=done: done.record(torch.cuda.current_stream()))
+            pending.append((x, out, done))                   # x stays referenced until its batch has been read
+        while pending:
+            yield self._collect(pending.pop(0))
+
+    @staticmethod
+    def _collect(item):
+        from ..utils.utils import split_detections
+        _, out, done = item
+        done.synchronize()
+        return split_detections(*out)
+
     def detect(self, x, conf_thres=0.5, nms_thres=0.5):
         """The composition inside reference test_model (utils/utils.py:374-378):
         ``non_max_suppression(model(x)[0], conf_thres, nms_thres)``."""

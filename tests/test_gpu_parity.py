@@ -1908,3 +1908,31 @@ def test_pipelined_detect_matches_joined_calls():
         assert torch.equal(w[2], g[2])
         for b, n in enumerate(w[2].tolist()):
             assert torch.equal(w[0][b, :n], g[0][b, :n]) and torch.equal(w[1][b, :n], g[1][b, :n])
+
+
+def test_detect_stream_yields_every_batch_in_order():
+    """model.detect_stream(): the pipelined serving loop behind a generator - every batch comes out, in order, with the detections
+    of the whole-batch launch list (= the one-stream model's detect()), whatever the number of batches (fewer than the ring,
+    odd, many); inputs produced on the caller's stream right before the call are waited for."""
+    from pytorch_yolo_amd.utils.synthetic import synth_images
+    case = C.MODEL_CASES["spp_kd2_nc80"]
+    model, sd, _ = build_case(case)
+    model = model.to(DEV)
+    ref, _, _ = build_case(case)
+    ref = ref.to(DEV)
+    ref.n_streams = 1
+    host = [synth_images(8, 96, 64, 50 + k) for k in range(7)]
+    with torch.no_grad():
+        want = [ref.detect(h.to(DEV), 1e-4, 0.5) for h in host]
+        for n in (1, 2, 7):
+            got = list(model.detect_stream((h.to(DEV, non_blocking=True) for h in host[:n]), 1e-4, 0.5))
+            assert len(got) == n
+            for w, g in zip(want, got):
+                assert len(w) == len(g) == 8
+                for a, b in zip(w, g):
+                    assert (a is None) == (b is None)
+                    if a is not None:
+                        assert torch.equal(a, b)
+    assert sum(d is not None for w in want for d in w) > 0
+    with pytest.raises(RuntimeError):
+        list(model.detect_stream([host[0].to(DEV), host[0][:4].to(DEV)], 1e-4, 0.5))
