@@ -349,7 +349,7 @@ def main():
     # API-level number beside the device-level one: model.detect() as a caller sees it (fresh output tensors every call, the
     # count D2H copy and the list[Tensor | None] split inside the timed region, host-synchronous); sharded runs time
     # detect_sharded (forward + NMS + all-gather + split on every rank)
-    api_ips = None
+    api_ips = stream_ips = None
     if not args.no_api:
         from pytorch_yolo_amd.distributed import detect_sharded
         k_api = max(3, min(args.steps, 20))
@@ -366,6 +366,16 @@ def main():
             dist.all_reduce(tb, op=dist.ReduceOp.MAX)
         api_ips = round(bs * world * k_api / float(tb.item()), 2)
         assert len(res) == bs * world
+        if not sharded:          # the same API pipelined: model.detect_stream() (two batches in flight, lists handed out one batch late)
+            with torch.no_grad():
+                for _ in model.detect_stream((x for _ in range(4)), CONF_THRES, NMS_THRES):
+                    pass
+                sync_all()
+                ta = time.perf_counter()
+                n_out = sum(len(r) for r in model.detect_stream((x for _ in range(2 * k_api)), CONF_THRES, NMS_THRES))
+                sync_all()
+                stream_ips = round(n_out / (time.perf_counter() - ta), 2)
+            assert n_out == bs * 2 * k_api
 
     with torch.no_grad():
         for i in range(args.warmup):
@@ -425,6 +435,8 @@ def main():
                 pass
         if api_ips is not None:
             cfg["detect_api_images_per_s"] = api_ips
+        if stream_ips is not None:
+            cfg["detect_stream_api_images_per_s"] = stream_ips
         if head_gain is not None:
             cfg["synthetic_head_gain"] = round(head_gain, 3)
         out = {
