@@ -366,7 +366,7 @@ def main():
             dist.all_reduce(tb, op=dist.ReduceOp.MAX)
         api_ips = round(bs * world * k_api / float(tb.item()), 2)
         assert len(res) == bs * world
-        if not sharded:          # the same API pipelined: model.detect_stream() (two batches in flight, lists handed out one batch late)
+        if not sharded and os.environ.get("YOLO_BENCH_SKIP_STREAM_API") != "1":          # the same API pipelined: model.detect_stream() (two batches in flight, lists handed out one batch late)
             with torch.no_grad():
                 for _ in model.detect_stream((x for _ in range(4)), CONF_THRES, NMS_THRES):
                     pass
