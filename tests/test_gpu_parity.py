@@ -1936,3 +1936,12 @@ def test_detect_stream_yields_every_batch_in_order():
     assert sum(d is not None for w in want for d in w) > 0
     with pytest.raises(RuntimeError):
         list(model.detect_stream([host[0].to(DEV), host[0][:4].to(DEV)], 1e-4, 0.5))
+    # a batch too small to split (one plain Plan, launches on the caller's stream): the same generator, the same lists
+    small = [h[:2] for h in host[:3]]
+    with torch.no_grad():
+        assert type(model.plan_for(small[0].to(DEV))).__name__ == "Plan"
+        want_s = [ref.detect(h.to(DEV), 1e-4, 0.5) for h in small]
+        got_s = list(model.detect_stream((h.to(DEV) for h in small), 1e-4, 0.5))
+    for w, g in zip(want_s, got_s):
+        for a, b in zip(w, g):
+            assert (a is None) == (b is None) and (a is None or torch.equal(a, b))
