@@ -21,6 +21,7 @@ SOURCES = {
     "conv3x3_halo.hip": [],
     "conv3x3_t20.hip": [],
     "conv_resunit.hip": [],
+    "conv_resunit_t20.hip": [],
     "conv_stem.hip": [],
     "conv_mbconv.hip": [],
     "conv_small.hip": [],

@@ -1,0 +1,288 @@
+// The 64-channel residual unit of the Darknet stem stage (reference models/yolov3_spp.py:17-32: y = x + act(conv3x3(act(conv1x1(x)))),
+// 64 -> 32 -> 64 channels on the 320x320 maps of a 640x640 input) on 20x20 output tiles, with the machinery of conv3x3_t20.hip:
+// same contract and rounding points as yolo_resunit_fwd's other kernels (the 32-channel intermediate is rounded to bf16 once,
+// the sum with x is formed in fp32 and rounded once).
+//
+//   workgroup   4 waves, one 20x20 tile, all 64 couts; two workgroups per CU (64 KB of LDS, <= 256 registers)
+//   phase A     the 22x22 halo of x arrives as two 32-channel chunk images [484 pixel rows of 64 B] by LDS-DMA (16 per wave, all
+//               in flight at once).  A wave multiplies exactly the rows it fetched itself - 8 pieces of 16 pixels - with W1
+//               (32 couts x 64 k: four fragments, in registers): 32 MFMAs, no barrier in front.  bias + act, zero outside the image
+//               (the 3x3 zero-pads the INTERMEDIATE), bf16, written IN PLACE over its own rows of chunk image 0: that image now
+//               is the 3x3's halo in conv3x3_t20's layout (slot = 8-channel group ^ 2 * (halo row & 1)).
+//   phase B     one barrier, then the nine taps with all of W2 (64 couts x 288 k) in registers: wave = (cout half, patch parity),
+//               32 couts x 13 (12) of the 25 4x4-pixel patches, fragment addresses = per-lane base + compile-time constants.
+//               234 (216) MFMAs per wave, no barrier, no global traffic.
+//   epilogue    patch pairs (even patch from waves 0/1, odd from 2/3) staged as [32 pixels][64 couts] fp32 in the idle second
+//               chunk image, one raw barrier per pair; every lane then owns 8 couts of one pixel: residual (x, L2-hot) added in
+//               fp32, 16-byte buffer stores over whole 128-byte pixel rows, residual rows requested three pairs ahead.
+// Per tile the CU moves 62 KB in + 51 KB out (+ 51 KB of residual from L2) for 1,024 MFMAs: 0.93 GB per 32 images of 320x320, a
+// floor of ~0.17 ms at 5.5 TB/s.  Measured 0.318 ms (the persistent 16x16-tile kernel of conv_resunit.hip: 0.365 ms): a workgroup
+// is a load -> 1x1 -> 3x3 -> store chain and only two fit a CU.  Tried and dropped: a persistent form that fetches the next
+// tile's halo straight into MFMA operand registers during the epilogue (no LDS for x, 48 KB per workgroup) - 0.370 ms: in the
+// operand layout the four lanes that share a pixel row are 16 lanes apart, so a load instruction makes 64 separate 16-byte
+// requests where the LDS-DMA layout makes 16 of 64 bytes, and hoisted per-lane address constants pushed it into spills.
+#include "conv_common.h"
+
+using namespace yolo_conv;
+
+namespace {
+
+constexpr int kT = 20, kHW = 22, kHPix = kHW * kHW;     // tile edge, halo edge, halo pixels
+constexpr int kBuf = 32 * 1024;                          // one chunk image: 32 pieces of 16 rows of 64 B (31 used)
+constexpr int kPitch = 272;                              // fp32 staging row: 64 couts + 16 B
+constexpr int kSlab = 32 * kPitch;
+static_assert(2 * kSlab <= kBuf, "the epilogue slabs live in the second chunk image");
+
+struct RU20Args {
+  ConvArgs c;           // the 3x3: w = W2, bias = b2, res = x view, y, aux; d.cin = 32, d.cout = 64
+  const bf16_t* w1;     // packed [cout_pad1][kpad1], K = 64
+  const float* b1;
+  int kpad1;
+  uint32_t w1_bytes;
+};
+
+__global__ __launch_bounds__(256, 2) void resunit64_t20_kernel(const RU20Args ra) {
+  constexpr int RD = 3;                                  // residual rows in flight in the epilogue (patch pairs ahead)
+  __shared__ __attribute__((aligned(16))) char smem[2 * kBuf];
+  const ConvArgs& a = ra.c;
+  const YoloConvDesc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_x = (d.w + kT - 1) / kT, tiles_y = (d.h + kT - 1) / kT;
+  int b, y0, x0;
+  {
+    int swz = xcd_swizzle(blockIdx.x, gridDim.x);
+    x0 = (swz % tiles_x) * kT;
+    swz /= tiles_x;
+    y0 = (swz % tiles_y) * kT;
+    b = swz / tiles_y;
+  }
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw1 = __builtin_amdgcn_make_buffer_rsrc((void*)ra.w1, 0, ra.w1_bytes, 0x00020000);
+
+  // ---- the x halo: piece (it * 4 + wave) = LDS rows [16 piece, +16); lane -> (row lane >> 2, physical slot lane & 3)
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int piece = it * 4 + wave;
+    const int hp = piece * 16 + (lane >> 2);
+    const int hy = hp / kHW, hx = hp - hy * kHW;
+    const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+    const int chunk = (lane & 3) ^ ((hy & 1) << 1);
+    const bool ok = hp < kHPix && (unsigned)yy < (unsigned)d.h && (unsigned)xx < (unsigned)d.w;
+    const uint32_t ho = ok ? (uint32_t)((((b * d.h + yy) * d.w + xx) * d.in_c_total + d.in_c_offset + chunk * 8) * 2) : kOobOffset;
+    lds_dma16s(rx, smem + piece * 1024, ho, 0u);             // channels 0..31
+    lds_dma16s(rx, smem + kBuf + piece * 1024, ho, 64u);     // channels 32..63
+  }
+
+  const int c16 = lane & 15, q = lane >> 4;
+  auto mfma = [&](f32x4& t, const bf16x8& wa, const bf16x8& xb) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(t) : "v"(wa), "v"(xb));
+#endif
+  };
+  const bool floor0 = d.act == YOLO_ACT_RELU || d.act == YOLO_ACT_RELU6;
+  const float slope = d.act == YOLO_ACT_LEAKY01 ? 0.1f : 1.f;
+  const float hi_clamp = d.act == YOLO_ACT_RELU6 ? 6.f : __builtin_inff();
+  auto act4 = [&](f32x4 v) -> f32x4 {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], floor0 ? 0.f : slope * v[e]), hi_clamp);
+    return v;
+  };
+
+  // ---- phase A: intermediate[32 couts][my 8 x 16 halo pixels] = W1 x (both chunk images)
+  bf16x8 w1f[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+      w1f[i][kc] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                  rw1, (uint32_t)(((i * 16 + c16) * ra.kpad1 + kc * 32 + q * 8) * 2), 0, 0));
+  f32x4 b1v[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) b1v[i] = *reinterpret_cast<const f32x4*>(ra.b1 + i * 16 + q * 4);
+  uint32_t rowA[8];                                        // this lane's 16 bytes of piece `it`: row (piece * 16 + c16), k group q
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = (it * 4 + wave) * 16 + c16;
+    const int hy = row / kHW;
+    rowA[it] = (uint32_t)(row * 64 + ((q ^ ((hy & 1) << 1)) << 4));
+  }
+  f32x4 acc1[8][2];
+#pragma unroll
+  for (int it = 0; it < 8; ++it)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) acc1[it][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  wait_vmcnt<0>();                                         // my own DMA pieces (and W1) have landed: nobody else's rows are read here
+  static_for<2>([&](auto kcc) {
+    constexpr int kc = decltype(kcc)::value;
+    static_for<8>([&](auto itc) {
+      constexpr int it = decltype(itc)::value;
+      const bf16x8 xb = *reinterpret_cast<const bf16x8*>(smem + kc * kBuf + rowA[it]);
+      static_for<2>([&](auto ic) { mfma(acc1[it][decltype(ic)::value], w1f[decltype(ic)::value][kc], xb); });
+    });
+  });
+
+  // all of W2 for this wave: 32 couts (cout half cg) x 9 taps x 32 k; they land under phase A's epilogue
+  const int cg = wave & 1, pg = wave >> 1;
+  const uint32_t wv = (uint32_t)(((cg * 32 + c16) * d.kpad + q * 8) * 2);
+  const uint32_t wfrag = (uint32_t)(16 * d.kpad * 2);
+  bf16x8 wf[9][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      wf[t][i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, wv + (uint32_t)(t * 64) + i * wfrag, 0, 0));
+
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_nop 15\n\ts_nop 15");                  // the asm MFMAs' D registers: wait states before any other reader
+#endif
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = (it * 4 + wave) * 16 + c16;
+    const int hy = row / kHW, hx = row - hy * kHW;
+    const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+    const bool inimg = row < kHPix && (unsigned)yy < (unsigned)d.h && (unsigned)xx < (unsigned)d.w;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f32x4 v = act4(acc1[it][i] + b1v[i]);
+      if (!inimg) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+      // channels i * 16 + q * 4 + e: 8-channel group i * 2 + (q >> 1), second half of the slot for odd q
+      *reinterpret_cast<bf16x4*>(smem + row * 64 + (((i * 2 + (q >> 1)) ^ ((hy & 1) << 1)) << 4) + (q & 1) * 8) = o;
+    }
+  }
+  wait_lds();
+  __builtin_amdgcn_s_barrier();                            // chunk image 0 now holds the whole intermediate halo
+
+  // ---- phase B: the nine taps
+  const int dy = c16 >> 2, dx = c16 & 3;
+  uint32_t A[2];                                           // halo bases by parity of (dy + tap row)
+#pragma unroll
+  for (int par = 0; par < 2; ++par) A[par] = (uint32_t)((dy * kHW + dx) * 64 + ((q ^ (((dy + par) & 1) << 1)) << 4));
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(A[0]), "+v"(A[1]));
+#endif
+  auto xread = [&](int jj, int tap, uint32_t am) -> bf16x8 {
+    const char* const p = smem + am;
+    return *reinterpret_cast<const bf16x8*>(p + ((4 * (jj / 5)) * kHW + 4 * (jj % 5)) * 64 + ((tap / 3) * kHW + tap % 3) * 64);
+  };
+
+  const uint32_t y_pitch = (uint32_t)d.out_c_total * 2u, r_pitch = (uint32_t)d.res_c_total * 2u, x_pitch = (uint32_t)d.aux_c_total * 2u;
+  const uint32_t npix = (uint32_t)d.n * d.h * d.w;
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, npix * y_pitch, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, npix * r_pitch, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rax = __builtin_amdgcn_make_buffer_rsrc((void*)a.aux, 0, a.aux ? npix * x_pitch : 0u, 0x00020000);
+
+  auto run = [&](auto pgc) {
+    constexpr int PG = decltype(pgc)::value;               // patches 2 k + PG
+    constexpr int NPW = PG ? 12 : 13, NSTEP = 9 * NPW, XD = 3;
+    f32x4 acc[2][NPW];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int k = 0; k < NPW; ++k) acc[i][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 xf[XD];
+#pragma unroll
+    for (int s = 0; s < XD - 1; ++s) xf[s] = xread(2 * (s % NPW) + PG, s / NPW, A[((s / NPW) / 3) & 1]);
+    static_for<NSTEP>([&](auto sc) {
+      constexpr int s = decltype(sc)::value, tap = s / NPW, k = s % NPW;
+      if constexpr (s + XD - 1 < NSTEP) {
+        constexpr int s2 = s + XD - 1, tap2 = s2 / NPW, k2 = s2 % NPW;
+        xf[s2 % XD] = xread(2 * k2 + PG, tap2, A[(tap2 / 3) & 1]);
+      }
+      static_for<2>([&](auto ic) { mfma(acc[decltype(ic)::value][k], wf[tap][decltype(ic)::value], xf[s % XD]); });
+    });
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_nop 15\n\ts_nop 15");
+#endif
+    if (a.debug & 8) return;
+
+    // ---- epilogue: pair r = patches 2 r (waves 0, 1) and 2 r + 1 (waves 2, 3)
+    f32x4 b2v[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b2v[i] = *reinterpret_cast<const f32x4*>(a.bias + cg * 32 + i * 16 + q * 4);
+    // coalesced phase: this wave stores half of ITS OWN patch of the pair: pixel rows 8 (wave & 1) + (lane >> 3), 8 couts per lane
+    const int prow = 8 * (wave & 1) + (lane >> 3), cch = lane & 7;
+    const int dyr = prow >> 2, dxr = prow & 3;
+    const uint32_t lpix = (uint32_t)((b * d.h + y0 + dyr) * d.w + x0 + dxr);
+    const uint32_t ccol = (uint32_t)(cch * 8) * 2u;
+    const uint32_t yo = lpix * y_pitch + (uint32_t)d.out_c_offset * 2u + ccol;
+    const uint32_t ro = lpix * r_pitch + (uint32_t)d.res_c_offset * 2u + ccol;
+    const uint32_t ao = lpix * x_pitch + (uint32_t)d.aux_c_offset * 2u + ccol;
+    const int ylim = d.h - y0 - dyr, xlim = d.w - x0 - dxr;
+    auto voff = [&](uint32_t base, uint32_t pitch, int jj) -> uint32_t {
+      const int pr = jj / 5, pc = jj % 5;
+      const bool ok = 4 * pr < ylim && 4 * pc < xlim;
+      return ok ? base + (uint32_t)(4 * pr * d.w + 4 * pc) * pitch : kOobOffset;
+    };
+    u32x4 rv[RD + 1];
+    auto fetch_res = [&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      rv[r % (RD + 1)] = __builtin_amdgcn_raw_buffer_load_b128(rr, voff(ro, r_pitch, 2 * r + PG), 0, 0);
+    };
+    static_for<RD>([&](auto rc) { fetch_res(rc); });
+    static_for<13>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      char* const slab = smem + kBuf + (r & 1) * kSlab;
+      if constexpr (r < NPW) {
+        static_for<2>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          *reinterpret_cast<f32x4*>(slab + (PG * 16 + c16) * kPitch + (cg * 32 + i * 16 + q * 4) * 4) = act4(acc[i][r] + b2v[i]);
+        });
+      }
+      if constexpr (r + RD < NPW) fetch_res(std::integral_constant<int, r + RD>{});
+      wait_lds();
+      __builtin_amdgcn_s_barrier();                        // the pair is staged by all four waves (and pair r - 1 has been read by all)
+      if constexpr (r < NPW) {
+        const int row = PG * 16 + prow;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + row * kPitch + cch * 32);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + row * kPitch + cch * 32 + 16);
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if (a.aux) {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rax, voff(ao, x_pitch, 2 * r + PG), 0, 0);
+        }
+        const bf16x8 r8 = __builtin_bit_cast(bf16x8, rv[r % (RD + 1)]);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(v[e] + (float)r8[e]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, voff(yo, y_pitch, 2 * r + PG), 0, 0);
+      }
+    });
+  };
+  if (pg == 0) run(std::integral_constant<int, 0>{});
+  else run(std::integral_constant<int, 1>{});
+}
+
+}  // namespace
+
+namespace yolo_conv {
+
+// 1: not this kernel's case (the caller falls back to the 16x16-tile kernels)
+int launch_resunit64_t20(const ConvArgs& c, const bf16_t* w1, const float* b1, int kpad1, uint32_t w1_bytes, bool force, hipStream_t s) {
+  const YoloConvDesc& d = c.d;
+  if (d.cout != 64 || d.cin != 32 || d.act == YOLO_ACT_SWISH || !c.res) return 1;
+  const long tiles = (long)d.n * ((d.h + kT - 1) / kT) * ((d.w + kT - 1) / kT);
+  // partial tiles idle lanes; few tiles: the persistent 16x16-tile kernel (YOLO_RESUNIT_DEBUG bit 64 forces this one)
+  if (!force && ((double)d.n * d.h * d.w < 0.9 * 400.0 * tiles || tiles < 256)) return 1;
+  const size_t npix = (size_t)d.n * d.h * d.w;
+  if (npix * d.out_c_total * 2 >= kOobOffset || npix * d.res_c_total * 2 >= kOobOffset || (c.aux && npix * d.aux_c_total * 2 >= kOobOffset))
+    return 1;
+  if (tiles > 0x7fffffffL) return 1;
+  if (pick_only("resunit64_t20<400px x 64 couts, 4 waves> grid %ld", tiles)) return 0;
+  RU20Args ra;
+  ra.c = c;
+  ra.w1 = w1;
+  ra.b1 = b1;
+  ra.kpad1 = kpad1;
+  ra.w1_bytes = w1_bytes;
+  hipLaunchKernelGGL(resunit64_t20_kernel, dim3((unsigned)tiles), dim3(256), 0, s, ra);
+  return yolo_check_launch("yolo_resunit_fwd(t20)");
+}
+
+}  // namespace yolo_conv

@@ -157,7 +157,10 @@ def test_conv_tile_configurations(case):
 
 
 @pytest.mark.parametrize("n,h,w,c,use_aux", [(1, 80, 80, 256, False), (2, 96, 80, 128, True), (1, 94, 100, 64, False),
-                                              (2, 80, 112, 256, True), (3, 96, 160, 64, True), (16, 320, 320, 64, False)])
+                                              (2, 80, 112, 256, True), (3, 96, 160, 64, True), (16, 320, 320, 64, False),
+                                              # >= 256 tiles of 20x20 covering >= 90 % of the map: conv_resunit_t20.hip (whole tiles
+                                              # with the pre-add copy; partial edge tiles in both directions)
+                                              (3, 200, 200, 64, True), (3, 190, 230, 64, True), (4, 163, 178, 64, False)])
 def test_fused_residual_unit(n, h, w, c, use_aux):
     """yolo_resunit_fwd (1x1 -> 3x3 -> add in one launch) against fp32 torch on the same bf16-rounded operands
     (the 1x1 output rounded to bf16 like the stored intermediate of the two-kernel path), and against the
