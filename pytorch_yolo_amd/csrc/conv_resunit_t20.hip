@@ -184,23 +184,7 @@ __global__ __launch_bounds__(256, 2) void resunit64_t20_kernel(const RU20Args ra
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int k = 0; k < NPW; ++k) acc[i][k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 xf[XD];
-#pragma unroll
-    for (int s = 0; s < XD - 1; ++s) xf[s] = xread(2 * (s % NPW) + PG, s / NPW, A[((s / NPW) / 3) & 1]);
-    static_for<NSTEP>([&](auto sc) {
-      constexpr int s = decltype(sc)::value, tap = s / NPW, k = s % NPW;
-      if constexpr (s + XD - 1 < NSTEP) {
-        constexpr int s2 = s + XD - 1, tap2 = s2 / NPW, k2 = s2 % NPW;
-        xf[s2 % XD] = xread(2 * k2 + PG, tap2, A[(tap2 / 3) & 1]);
-      }
-      static_for<2>([&](auto ic) { mfma(acc[decltype(ic)::value][k], wf[tap][decltype(ic)::value], xf[s % XD]); });
-    });
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_nop 15\n\ts_nop 15");
-#endif
-    if (a.debug & 8) return;
-
-    // ---- epilogue: pair r = patches 2 r (waves 0, 1) and 2 r + 1 (waves 2, 3)
+    // ---- epilogue addressing, and the first residual rows: requested before the nine taps, they land under them
     f32x4 b2v[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) b2v[i] = *reinterpret_cast<const f32x4*>(a.bias + cg * 32 + i * 16 + q * 4);
@@ -224,6 +208,23 @@ __global__ __launch_bounds__(256, 2) void resunit64_t20_kernel(const RU20Args ra
       rv[r % (RD + 1)] = __builtin_amdgcn_raw_buffer_load_b128(rr, voff(ro, r_pitch, 2 * r + PG), 0, 0);
     };
     static_for<RD>([&](auto rc) { fetch_res(rc); });
+    bf16x8 xf[XD];
+#pragma unroll
+    for (int s = 0; s < XD - 1; ++s) xf[s] = xread(2 * (s % NPW) + PG, s / NPW, A[((s / NPW) / 3) & 1]);
+    static_for<NSTEP>([&](auto sc) {
+      constexpr int s = decltype(sc)::value, tap = s / NPW, k = s % NPW;
+      if constexpr (s + XD - 1 < NSTEP) {
+        constexpr int s2 = s + XD - 1, tap2 = s2 / NPW, k2 = s2 % NPW;
+        xf[s2 % XD] = xread(2 * k2 + PG, tap2, A[(tap2 / 3) & 1]);
+      }
+      static_for<2>([&](auto ic) { mfma(acc[decltype(ic)::value][k], wf[tap][decltype(ic)::value], xf[s % XD]); });
+    });
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_nop 15\n\ts_nop 15");
+#endif
+    if (a.debug & 8) return;
+
+    // ---- epilogue: pair r = patches 2 r (waves 0, 1) and 2 r + 1 (waves 2, 3)
     static_for<13>([&](auto rc) {
       constexpr int r = decltype(rc)::value;
       char* const slab = smem + kBuf + (r & 1) * kSlab;
