@@ -74,16 +74,29 @@ def nms_launch(prediction, conf_thres, nms_thres, out, slot=0, inplace_conf=Fals
 
 
 def split_detections(dets, idx, count, with_indices=False):
-    """Device buffers -> the reference's ``list[Tensor[n,7] | None]`` (one D2H copy of the counts)."""
+    """Device buffers -> the reference's ``list[Tensor[n,7] | None]`` (one D2H copy of the counts).  The kept rows of all
+    images are gathered into ONE packed tensor (an index built on the host, one index_select) and handed out as its per-image
+    slices: two launches per call instead of one clone per image, and the big output buffers are not kept alive."""
     counts = count.cpu().tolist()
     cap = dets.shape[1]
-    out, out_idx = [], []
     for b, n in enumerate(counts):
         if n > cap:
             raise RuntimeError(f"image {b}: {n} detections exceed the output capacity {cap}")
-        out.append(dets[b, :n].clone() if n else None)
-        out_idx.append(idx[b, :n].clone().long() if n else None)
-    return (out, out_idx) if with_indices else out
+    total = sum(counts)
+    if total == 0:
+        out = [None] * len(counts)
+        return (out, list(out)) if with_indices else out
+    import numpy as np
+    rows = np.concatenate([np.arange(b * cap, b * cap + n, dtype=np.int64) for b, n in enumerate(counts) if n])
+    rows = torch.from_numpy(rows).to(dets.device, non_blocking=True)
+    packed = dets.reshape(-1, dets.shape[2]).index_select(0, rows)
+    parts = iter(torch.split(packed, [n for n in counts if n]))
+    out = [next(parts) if n else None for n in counts]
+    if not with_indices:
+        return out
+    packed_idx = idx.reshape(-1).index_select(0, rows).long()
+    parts = iter(torch.split(packed_idx, [n for n in counts if n]))
+    return out, [next(parts) if n else None for n in counts]
 
 
 def non_max_suppression(prediction, conf_thres=0.5, nms_thres=0.5, inplace_conf=False, with_indices=False):
