@@ -11,6 +11,8 @@ Tolerances (stated once, used below):
   * whole model in bf16 vs the fp32 oracle: boxes within max(1.5 px, 2 %), scores within 2e-2 (4e-2 for YOLOv3, see there)
     (bf16 activations through up to 75 conv layers); measured values are printed.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1948,3 +1950,33 @@ def test_detect_stream_yields_every_batch_in_order():
     for w, g in zip(want_s, got_s):
         for a, b in zip(w, g):
             assert (a is None) == (b is None) and (a is None or torch.equal(a, b))
+
+
+@pytest.mark.parametrize("extra", [(), ("--pipeline", "halves", "--no-api")])
+def test_bench_line_contract(extra):
+    """bench.py as the driver runs it (a child process, one JSON line on stdout): the contract keys, the roofline object and the
+    echo of --steps / --warmup, on the small workload in both pipeline modes."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "tiny", "--steps", "6", "--warmup", "2",
+                        "--no-cpu-baseline", *extra], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] * 1e-3 / d["config"]["images_per_gpu"] - 1.0) < 1e-3
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] in ("hbm", "mfma") and 0 < rf["frac"] < 1 and abs(rf["achieved"] / rf["peak"] - rf["frac"]) < 1e-3
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["config"]["pipelines"].startswith("2 x " + ("sub-batches" if extra else "whole batches"))
+    assert d["config"]["mean_detections_per_image"] > 0
+    if not extra:
+        assert d["config"]["detect_api_images_per_s"] > 0 and d["config"]["detect_stream_api_images_per_s"] > 0
