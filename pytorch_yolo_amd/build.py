@@ -48,19 +48,26 @@ def build(force: bool = False, verbose: bool = False) -> str:
     headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_common.h"),
                os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "yolo_hip.h"),
                os.path.abspath(__file__)]        # per-file flags live here: a flag change rebuilds too
-    objs = []
+    objs, jobs = [], []
     for src, extra in SOURCES.items():
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [HIPCC, *COMMON, *extra, "-c", s, "-o", o]
-            if verbose:
-                print(" ".join(cmd), flush=True)
+            jobs.append([HIPCC, *COMMON, *extra, "-c", s, "-o", o])
             for stale in (o, LIB_PATH):          # never leave an out-of-date library behind a failed build
                 if os.path.exists(stale):
                     os.remove(stale)
-            subprocess.run(cmd, check=True)
+
+    def compile_one(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    if jobs:        # one hipcc per source, a few at a time (YOLO_BUILD_JOBS; the files are independent)
+        from concurrent.futures import ThreadPoolExecutor
+        workers = max(1, min(len(jobs), int(os.environ.get("YOLO_BUILD_JOBS", str(min(6, os.cpu_count() or 1))))))
+        with ThreadPoolExecutor(workers) as pool:
+            list(pool.map(compile_one, jobs))
     if force or _stale(LIB_PATH, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
         if verbose:

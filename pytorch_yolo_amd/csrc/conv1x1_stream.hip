@@ -23,7 +23,7 @@ struct ActParams {
   float slope, hi;
   __device__ explicit ActParams(int act)
       : floor0(act == YOLO_ACT_RELU || act == YOLO_ACT_RELU6), swish(act == YOLO_ACT_SWISH), slope(act == YOLO_ACT_LEAKY01 ? 0.1f : 1.f),
-        hi(act == YOLO_ACT_RELU6 ? 6.f : __builtin_inff()) {}
+        hi(act_hi(act)) {}
   __device__ __forceinline__ float plain(float v) const { return fminf(fmaxf(v, floor0 ? 0.f : slope * v), hi); }
 };
 

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(64 * (CT / 64) * NWM) void conv3x3_t20_kernel(const
   // apply_act (up to the sign of a zero) without a per-element switch on d.act
   const bool floor0 = d.act == YOLO_ACT_RELU || d.act == YOLO_ACT_RELU6;
   const float slope = d.act == YOLO_ACT_LEAKY01 ? 0.1f : 1.f;
-  const float hi_clamp = d.act == YOLO_ACT_RELU6 ? 6.f : __builtin_inff();
+  const float hi_clamp = act_hi(d.act);
   auto act4 = [&](f32x4 v) -> f32x4 {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], floor0 ? 0.f : slope * v[e]), hi_clamp);
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_t20v2_kernel(const ConvArgs a)
   for (int i = 0; i < 2; ++i) bv[i] = *reinterpret_cast<const f32x4*>(a.bias + n0 + wave * 32 + i * 16 + q * 4);
   const bool floor0 = d.act == YOLO_ACT_RELU || d.act == YOLO_ACT_RELU6;
   const float slope = d.act == YOLO_ACT_LEAKY01 ? 0.1f : 1.f;
-  const float hi_clamp = d.act == YOLO_ACT_RELU6 ? 6.f : __builtin_inff();
+  const float hi_clamp = act_hi(d.act);
   auto act4 = [&](f32x4 v) -> f32x4 {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], floor0 ? 0.f : slope * v[e]), hi_clamp);

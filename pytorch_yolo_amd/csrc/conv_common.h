@@ -117,17 +117,23 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds
 // 32x32x16 fragment shapes.
 __device__ __forceinline__ int swz32(int v) { return (0x78 >> (2 * (v & 3))) & 3; }
 
+// Upper operand of the activation formula min(max(v, lo), hi): 6 for ReLU6, otherwise a quiet NaN.  v_min_f32 / fminf return the
+// OTHER operand when one of the two is a NaN, so min(r, NaN) = r for every r and a NaN pre-activation stays a NaN.  (With +inf as
+// the "no clamp" value fminf(NaN, inf) = inf: a NaN logit of a plain head decoded to confidence 1, where the reference keeps the
+// NaN and its `conf > thres` drops the row.)
+__device__ __forceinline__ float act_hi(int act) { return act == YOLO_ACT_RELU6 ? 6.f : __builtin_nanf(""); }
+
 // act(v + bias) of the conv epilogues.  ONE data-independent formula covers none / LeakyReLU(0.1) / ReLU / ReLU6:
 // min(max(v, lo), hi) with lo = 0 or slope * v - the selects are wave-uniform and loop-invariant, so an unrolled epilogue pays
 // 4 VALU per value.  (As a chain of `if (act == ...) return ...` every one of a tile's 64-256 values carried its own tree of
 // scalar compares and branches: ~10 s_cbranch per value, more cycles than the MFMAs of a short-K layer.)  Same bits as the chain
-// for every input: the expressions per activation are the ones it evaluated.  swish (x * sigmoid(x)) keeps a uniform branch.
+// for every finite input and for +-inf; a NaN stays a NaN under none / LeakyReLU (max(NaN, slope * NaN) = NaN) and becomes 0 under
+// ReLU / ReLU6 (max(NaN, 0) = 0, as `v > 0 ? v : 0` gave).  swish (x * sigmoid(x)) keeps a uniform branch.
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == YOLO_ACT_SWISH) return v / (1.f + expf(-v));
   const bool floor0 = act == YOLO_ACT_RELU || act == YOLO_ACT_RELU6;
   const float slope = act == YOLO_ACT_LEAKY01 ? 0.1f : 1.f;
-  const float hi = act == YOLO_ACT_RELU6 ? 6.f : __builtin_inff();
-  return fminf(fmaxf(v, floor0 ? 0.f : slope * v), hi);
+  return fminf(fmaxf(v, floor0 ? 0.f : slope * v), act_hi(act));
 }
 
 template <int N>

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void resunit64_t20_kernel(const RU20Args ra
   };
   const bool floor0 = d.act == YOLO_ACT_RELU || d.act == YOLO_ACT_RELU6;
   const float slope = d.act == YOLO_ACT_LEAKY01 ? 0.1f : 1.f;
-  const float hi_clamp = d.act == YOLO_ACT_RELU6 ? 6.f : __builtin_inff();
+  const float hi_clamp = act_hi(d.act);
   auto act4 = [&](f32x4 v) -> f32x4 {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], floor0 ? 0.f : slope * v[e]), hi_clamp);

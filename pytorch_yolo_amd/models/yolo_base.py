@@ -240,36 +240,46 @@ class YOLOBase(nn.Module):
         from ..utils.utils import nms_capacity, split_detections
         if self.training:
             raise NotImplementedError("detect_stream() is an inference call: .eval() first")
-        ring, pending, plan, shape = [], [], None, None
-        for x in batches:
-            x = x.float().contiguous()
-            if shape is None:
-                shape = tuple(x.shape)
-                plan = self.plan_for(x)
-                depth = max(2, plan.n_streams)
-                cap = nms_capacity(plan.rows_total, self.n_class)
+        ring, pending, plan, shape, dev = [], [], None, None, None
+        # Every batch is launched on the pipeline / NMS side streams (join=False) into buffers of ``ring`` that this generator
+        # owns; the caching allocator knows nothing about those streams.  So nothing may leave this frame - the consumer breaking
+        # out (GeneratorExit), an exception in the consumer, the shape check below - while a launched batch is still running:
+        # its io / out blocks would be handed to the next allocation and be overwritten by the kernels in flight.
+        try:
+            for x in batches:
+                x = x.float().contiguous()
+                if shape is None:
+                    shape, dev = tuple(x.shape), x.device
+                    plan = self.plan_for(x)
+                    depth = max(2, plan.n_streams)
+                    cap = nms_capacity(plan.rows_total, self.n_class)
+                    with torch.cuda.device(x.device):
+                        for _ in range(depth):
+                            io, ps = plan.new_outputs(want_p=False)
+                            out = (torch.empty((shape[0], cap, 7), dtype=torch.float32, device=x.device),
+                                   torch.empty((shape[0], cap), dtype=torch.int32, device=x.device),
+                                   torch.empty((shape[0],), dtype=torch.int32, device=x.device))
+                            ring.append((io, ps, out, torch.cuda.Event()))
+                elif tuple(x.shape) != shape or x.device != dev:
+                    raise RuntimeError(f"detect_stream: batch {tuple(x.shape)} on {x.device} differs from the first one "
+                                       f"{shape} on {dev}")
+                while len(pending) >= len(ring):               # the oldest batch's buffers are needed again: hand it out first
+                    yield self._collect(pending.pop(0))
+                k = self.__dict__.setdefault("_stream_calls", 0)
+                self._stream_calls = k + 1
+                io, ps, out, done = ring[k % len(ring)]
                 with torch.cuda.device(x.device):
-                    for _ in range(depth):
-                        io, ps = plan.new_outputs(want_p=False)
-                        out = (torch.empty((shape[0], cap, 7), dtype=torch.float32, device=x.device),
-                               torch.empty((shape[0], cap), dtype=torch.int32, device=x.device),
-                               torch.empty((shape[0],), dtype=torch.int32, device=x.device))
-                        ring.append((io, ps, out, torch.cuda.Event()))
-            elif tuple(x.shape) != shape:
-                raise RuntimeError(f"detect_stream: batch shape {tuple(x.shape)} differs from the first one {shape}")
-            while len(pending) >= len(ring):               # the oldest batch's buffers are needed again: hand it out first
+                    ready = torch.cuda.Event()
+                    ready.record()                               # x was produced on the caller's stream: the pipeline waits for it
+                    pending.append((x, out, done))               # (before the launch: a launch that fails half way is drained too)
+                    plan.launch_detect(x, io, ps, out, conf_thres, nms_thres, join=False, whole_batch=True, wait_for=ready,
+                                       after_nms=lambda i, lo, hi, done=done: done.record(torch.cuda.current_stream()))
+            while pending:
                 yield self._collect(pending.pop(0))
-            k = self.__dict__.setdefault("_stream_calls", 0)
-            self._stream_calls = k + 1
-            io, ps, out, done = ring[k % len(ring)]
-            with torch.cuda.device(x.device):
-                ready = torch.cuda.Event()
-                ready.record()                               # x was produced on the caller's stream: the pipeline waits for it
-                plan.launch_detect(x, io, ps, out, conf_thres, nms_thres, join=False, whole_batch=True, wait_for=ready,
-                                   after_nms=lambda i, lo, hi, done=done: done.record(torch.cuda.current_stream()))
-            pending.append((x, out, done))                   # x stays referenced until its batch has been read
-        while pending:
-            yield self._collect(pending.pop(0))
+        finally:
+            if pending and dev is not None:                      # abnormal exit with batches in flight: drain before ring dies
+                torch.cuda.synchronize(dev)
+                pending.clear()
 
     @staticmethod
     def _collect(item):

@@ -121,6 +121,36 @@ def test_conv_kernel(case):
         assert torch.all(aux[..., :8] == -77.0)
 
 
+@pytest.mark.parametrize("shape", [(1, 13, 13, 256, 255, 1, "none", True),      # plain fp32 head (direct per-lane epilogue)
+                                   (1, 40, 40, 64, 128, 3, "leaky", False),      # conv3x3_t20v2 epilogue
+                                   (1, 20, 20, 128, 64, 1, "leaky", False),      # LDS-staged gather epilogue
+                                   (2, 80, 80, 256, 128, 1, "none", False)])     # conv1x1_stream epilogue
+def test_conv_epilogue_keeps_nan_and_inf(shape):
+    """A NaN / +-inf pre-activation leaves the epilogue as NaN / +-inf under `none` and LeakyReLU, as in the reference's
+    Conv2d -> BatchNorm2d -> LeakyReLU (models/yolo_base.py:31-38): the data-independent min(max(v, lo), hi) form once turned a NaN
+    into +inf, which a plain head then decoded to a confidence-1 detection.  Injected through the bias of three couts."""
+    from pytorch_yolo_amd import kernels as K
+    from pytorch_yolo_amd._lib import ACT_LEAKY01, ACT_NONE, DT_BF16, DT_F32
+    n, h, w, cin, cout, k, act, f32 = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    bias[3], bias[17], bias[cout - 2] = float("nan"), float("inf"), float("-inf")
+    y = torch.zeros(n, h, w, K.roundup(cout, 8), dtype=torch.float32 if f32 else torch.bfloat16, device=DEV)
+    wp, bp, kpad, cout_pad = K.pack_conv_weight(wt, bias, cin)
+    d = K.conv_desc(n=n, h=h, w=w, cin=cin, in_c_total=cin, in_c_offset=0, cout=cout, out_c_total=y.shape[-1], out_c_offset=0,
+                    ksize=k, stride=1, act={"leaky": ACT_LEAKY01, "none": ACT_NONE}[act], kpad=kpad, cout_pad=cout_pad,
+                    out_dtype=DT_F32 if f32 else DT_BF16)
+    K.conv2d(_nhwc(x), wp.to(DEV), bp.to(DEV), y, d)
+    torch.cuda.synchronize()
+    got = y.float().cpu()
+    assert torch.isnan(got[..., 3]).all()
+    assert (got[..., 17] == float("inf")).all() and (got[..., cout - 2] == float("-inf")).all()
+    keep = [c for c in range(cout) if c not in (3, 17, cout - 2)]
+    assert torch.isfinite(got[..., keep]).all()
+
+
 BIG_CONV_CASES = [
     # shapes of the SPP-640 layer list at 16 images: each one selects a different tile configuration in yolo_conv2d_launch
     (16, 20, 20, 1024, 512, 1, True),     # 8-wave 128x128 tiles, three-stage ring (1x1 on the 20x20 maps)
@@ -1939,8 +1969,17 @@ def test_detect_stream_yields_every_batch_in_order():
                     if a is not None:
                         assert torch.equal(a, b)
     assert sum(d is not None for w in want for d in w) > 0
+    def idle():      # nothing of a dropped generator may still be running: its output ring goes back to the allocator
+        plan = model.plan_for(host[0].to(DEV))
+        sts = list(plan.streams) + list(plan._full_streams or []) + [plan._nms_stream]
+        return all(st is None or st.query() for st in sts)
     with pytest.raises(RuntimeError):
         list(model.detect_stream([host[0].to(DEV), host[0][:4].to(DEV)], 1e-4, 0.5))
+    assert idle()                                    # the shape error was raised with batch 0 in flight
+    gen = model.detect_stream((h.to(DEV) for h in host), 1e-4, 0.5)
+    first = next(gen)                                # batches 0..2 launched, 0 handed out; the consumer walks away
+    gen.close()
+    assert idle() and len(first) == 8
     # a batch too small to split (one plain Plan, launches on the caller's stream): the same generator, the same lists
     small = [h[:2] for h in host[:3]]
     with torch.no_grad():
