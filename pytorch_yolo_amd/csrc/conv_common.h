@@ -303,7 +303,7 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nblk) {
 
 // yolo_conv2d_pick (the tile-rule regression guard): while pick_buffer() is non-null the launch functions write the name of the
 // kernel instance they would launch there and return 0 WITHOUT launching (no GPU needed).
-int launch_resunit64_t20(const ConvArgs& c, const bf16_t* w1, const float* b1, int kpad1, uint32_t w1_bytes, bool force, hipStream_t s);
+int launch_resunit_t20(const ConvArgs& c, const bf16_t* w1, const float* b1, int kpad1, uint32_t w1_bytes, bool force, hipStream_t s);
 int launch_cus();                  // compute units the coming launches may use (256, or a CU-masked stream's share)
 char* pick_buffer();
 bool pick_only(const char* fmt, ...);   // true (and the name recorded) in pick mode

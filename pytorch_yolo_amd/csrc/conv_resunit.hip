@@ -618,8 +618,8 @@ extern "C" int yolo_resunit_fwd(const void* x, const void* w1_packed, const floa
   ra.b1 = b1;
   ra.kpad1 = kpad1;
   ra.w1_bytes = (uint32_t)w1_bytes;
-  if (C == 64 && !(ra.c.debug & 128)) {       // 20x20-tile kernel (conv_resunit_t20.hip) where tiles cover the map; bit 128: never, 64: always
-    const int rc = launch_resunit64_t20(ra.c, ra.w1, ra.b1, ra.kpad1, ra.w1_bytes, (ra.c.debug & 64) != 0, (hipStream_t)s);
+  if (!(ra.c.debug & 128)) {       // the 20-pixel-wide tile kernels (conv_resunit_t20.hip) where their tiles cover the map; bit 128: never, 64: always
+    const int rc = launch_resunit_t20(ra.c, ra.w1, ra.b1, ra.kpad1, ra.w1_bytes, (ra.c.debug & 64) != 0, (hipStream_t)s);
     if (rc != 1) return rc;
   }
   if (C == 64 && !(ra.c.debug & 32)) {        // persistent, software-pipelined form (YOLO_RESUNIT_DEBUG bit 32: generic kernel)

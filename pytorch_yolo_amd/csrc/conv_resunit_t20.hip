@@ -39,6 +39,7 @@ struct RU20Args {
   const float* b1;
   int kpad1;
   uint32_t w1_bytes;
+  int stagger;          // resunit_t20w_kernel: start-up delay of the first round's second workgroups, in ~2k-cycle sleeps
 };
 
 __global__ __launch_bounds__(256, 2) void resunit64_t20_kernel(const RU20Args ra) {
@@ -260,28 +261,423 @@ __global__ __launch_bounds__(256, 2) void resunit64_t20_kernel(const RU20Args ra
   else run(std::integral_constant<int, 1>{});
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The wider units (round 3): C = 128 on 160x160 maps and C = 256 on 80x80 maps of a 640x640 input (reference
+// models/yolov3_spp.py:17-46).  Same idea as the 64-channel kernel - the C/2-channel intermediate t lives in LDS only, the nine
+// taps run against it with conv3x3_t20v2's register-resident weight stream - generalised so that the WHOLE intermediate halo of a
+// tile fits 64 KB and TWO workgroups share a CU (one's x fetch and store phases run under the other's MFMA stream):
+//
+//   <CMID = 64, TPH = 5>    tile 20 x 20 (25 patches of 4 x 4), halo 22 x 22, t = 2 chunk images of 32 KB,
+//                           wave = 32 couts x 25 patches (200 accumulator registers) - conv3x3_t20v2's shape
+//   <CMID = 128, TPH = 2>   tile 20 x 8 (10 patches), halo 22 x 10, t = 4 chunk images of 16 KB,
+//                           wave = 64 couts x 10 patches (160 accumulator registers): all 256 couts of a pixel in one workgroup,
+//                           so the intermediate is computed once per tile (a 20 x 20 tile would need 124 KB for t: one
+//                           workgroup per CU, every phase of it exposed)
+//
+//   phase A   x arrives as C / 32 chunk images [halo pixel rows of 64 B] by LDS-DMA through the CMID / 32 image buffers that
+//             later hold t.  A wave multiplies exactly the pixel rows it fetched itself (PPW pieces of 16) with W1 - no barrier,
+//             only its own counted vmcnt: chunk c is multiplied while chunks c + 1 .. are in flight, and buffer c % NB is
+//             refilled with chunk c + NB as soon as the wave's own fragment reads of it have returned.  W1's fragments of a chunk
+//             (CMID / 16 of them) come straight from L2 into registers, one chunk ahead.  bias + act, zero outside the image
+//             (the 3x3 zero-pads t, not x), bf16, written over the wave's own rows: the buffers now hold t in conv3x3_t20's
+//             layout (slot = 8-channel group ^ 2 * (halo row & 1)).
+//   phase B   one barrier, then (CMID / 32) x 9 steps of NFW x NP MFMAs per wave against the resident halo: W2 fragments by
+//             buffer_load two steps ahead in three register sets, pixel fragments by ds_read with compile-time offsets; no
+//             barrier, no LDS-DMA.
+//   epilogue  patch pairs (CT 128) / single patches (CT 256) staged as fp32 rows of all CT couts, x (L2 / Infinity-Cache hot)
+//             added in fp32, whole 256- / 512-byte pixel rows stored with 16-byte buffer stores, residual rows RD units ahead.
+// Rounding points = the two-launch path's: t rounded to bf16 once, conv + residual summed in fp32 and rounded once.
+template <int CMID, int TPH>
+struct RUW {
+  static constexpr int C = 2 * CMID;
+  static constexpr int HY = 4 * TPH + 2, HP = HY * kHW;            // halo rows, halo pixels
+  static constexpr int PIECES = (HP + 15) / 16, PPW = (PIECES + 3) / 4;
+  static constexpr int IMG_B = PPW * 4 * 1024;                      // one chunk image (incl. padding pieces)
+  static constexpr int NIMG = CMID / 32, NXC = C / 32, NF = CMID / 16;
+  static constexpr int NFW = C / 64, NP = 5 * TPH;                  // cout fragments per wave, patches
+  static constexpr int CT = C, U = CT == 128 ? 2 : 1;               // patches per staging unit
+  static constexpr int PITCH = CT * 4 + 16, SLAB = 16 * U * PITCH;
+  static constexpr int LDS_B = NIMG * IMG_B;
+  static_assert(2 * SLAB <= LDS_B, "the epilogue slabs live in the image buffers");
+  static_assert(LDS_B <= 80 * 1024, "two workgroups per CU");
+};
+
+// Diagnostic build only (-DYOLO_STAMPS, tools/ru_timeline.py): wave 0 of every workgroup records when it reached each phase
+// boundary (s_memrealtime, 100 MHz) - 8 words per workgroup in a buffer nothing else reads.
+#ifdef YOLO_STAMPS
+#define RU_STAMP(k)                                                                                                  \
+  do {                                                                                                               \
+    if (a.stamps && tid == 0) a.stamps[8 * (size_t)blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime();             \
+  } while (0)
+#else
+#define RU_STAMP(k)
+#endif
+
+template <int CMID, int TPH>
+__global__ __launch_bounds__(256, 2) void resunit_t20w_kernel(const RU20Args ra) {
+  using G = RUW<CMID, TPH>;
+  constexpr int PPW = G::PPW, IMG_B = G::IMG_B, NIMG = G::NIMG, NXC = G::NXC, NFW = G::NFW, NP = G::NP;
+  constexpr int NB = NIMG;                               // x staging buffers = the t images
+  constexpr int RD = 3, XD = 3;
+  __shared__ __attribute__((aligned(16))) char smem[G::LDS_B];
+  const ConvArgs& a = ra.c;
+  const YoloConvDesc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_x = (d.w + kT - 1) / kT, tiles_y = (d.h + 4 * TPH - 1) / (4 * TPH);
+  int b, y0, x0;
+  {
+    int swz = xcd_swizzle(blockIdx.x, gridDim.x);
+    x0 = (swz % tiles_x) * kT;
+    swz /= tiles_x;
+    y0 = (swz % tiles_y) * (4 * TPH);
+    b = swz / tiles_y;
+  }
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw1 = __builtin_amdgcn_make_buffer_rsrc((void*)ra.w1, 0, ra.w1_bytes, 0x00020000);
+  const int c16 = lane & 15, q = lane >> 4;
+
+  // ---- phase A addressing.  DMA: piece (it * 4 + wave) = LDS rows [16 piece, +16); lane -> (row lane >> 2, physical slot lane & 3)
+  uint32_t h_off[PPW];
+#pragma unroll
+  for (int it = 0; it < PPW; ++it) {
+    const int hp = (it * 4 + wave) * 16 + (lane >> 2);
+    const int hy = hp / kHW, hx = hp - hy * kHW;
+    const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+    const int chunk = (lane & 3) ^ ((hy & 1) << 1);
+    const bool ok = hp < G::HP && (unsigned)yy < (unsigned)d.h && (unsigned)xx < (unsigned)d.w;
+    h_off[it] = ok ? (uint32_t)((((b * d.h + yy) * d.w + xx) * d.in_c_total + d.in_c_offset + chunk * 8) * 2) : kOobOffset;
+  }
+  auto issue_x = [&](auto cc) {                            // chunk c of x -> buffer c % NB, this wave's pieces
+    constexpr int c = decltype(cc)::value;
+#pragma unroll
+    for (int it = 0; it < PPW; ++it) lds_dma16s(rx, smem + (c % NB) * IMG_B + (it * 4 + wave) * 1024, h_off[it], (uint32_t)(c * 64));
+  };
+  auto mfma = [&](f32x4& t, const bf16x8& wa, const bf16x8& xb) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(t) : "v"(wa), "v"(xb));
+#endif
+  };
+  const bool floor0 = d.act == YOLO_ACT_RELU || d.act == YOLO_ACT_RELU6;
+  const float slope = d.act == YOLO_ACT_LEAKY01 ? 0.1f : 1.f;
+  const float hi_clamp = act_hi(d.act);
+  auto act4 = [&](f32x4 v) -> f32x4 {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], floor0 ? 0.f : slope * v[e]), hi_clamp);
+    return v;
+  };
+
+  // Start-up stagger: the second workgroup of every CU in the first round of the grid (blocks 256 .. 511 under the round-robin
+  // dispatch; a guess that only ever costs time) starts late, so that from then on one workgroup of a CU fetches / stores while
+  // the other multiplies.  Without it the two run in lockstep - both wait for x, both multiply, both store - and a launch takes
+  // the SUM of its memory and matrix phases (measured: 0.114 ms without the epilogue, 0.179 ms with it on the 160x160 unit).
+  if (ra.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+    for (int i = 0; i < ra.stagger; ++i) __builtin_amdgcn_s_sleep(32);        // ~2k cycles each
+  }
+
+  // ---- phase A: W1-stationary, the couts of t split over the waves.  Wave w owns t channels [CMID / 4 * w, + CMID / 4): its NFA
+  // cout fragments of W1 for the WHOLE K sit in registers (loaded once, before any x is requested: vector-memory operations retire
+  // in issue order, and a W1 load issued behind an x DMA that is still on its way from HBM waits for it - the first version, which
+  // streamed W1 beside x chunk by chunk, paid an HBM round trip per step, and an x-stationary version that streamed W1 from L2
+  // one fragment ahead spent 10 us per tile on L2 round trips for 2 us of MFMAs).  x streams through the image buffers as a ring
+  // of 32-channel chunks (every wave fetches its pieces of a chunk; one barrier per chunk says "chunk c has landed for everybody
+  // and everybody is done with chunk c - 1", behind which the freed buffer is refilled), and each wave multiplies ALL pixel rows
+  // of the chunk: PIECES fragment reads and PIECES * NFA MFMAs per chunk.
+  constexpr int NFA = CMID / 64, PIECES = G::PIECES;
+  RU_STAMP(0);
+  bf16x8 w1f[NFA][NXC];
+#pragma unroll
+  for (int fa = 0; fa < NFA; ++fa)
+#pragma unroll
+    for (int kc = 0; kc < NXC; ++kc)
+      w1f[fa][kc] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                   rw1, (uint32_t)((((wave * NFA + fa) * 16 + c16) * ra.kpad1 + q * 8) * 2), (uint32_t)(kc * 64), 0));
+  f32x4 b1v[NFA];
+#pragma unroll
+  for (int fa = 0; fa < NFA; ++fa) b1v[fa] = *reinterpret_cast<const f32x4*>(ra.b1 + (wave * NFA + fa) * 16 + q * 4);
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" ::: "memory");                           // W1 / bias are requested BEFORE the x DMAs (and the counted waits below rely on
+#endif                                                     // the order: hipcc moves plain loads across the DMA builtins otherwise)
+  static_for<NB>([&](auto kc) { issue_x(kc); });
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" ::: "memory");
+#endif
+  // fragment address of piece p in a buffer: pixel row 16 p + c16, k group q (slot = q ^ 2 * (halo row & 1))
+  const uint32_t rA = (uint32_t)(c16 * 64);
+  f32x4 acc1[PIECES][NFA];
+  static_for<NXC>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    // DMAs of this wave younger than chunk c's: chunks c + 1 .. min(c - 2 + NB, NXC - 1) (step k >= 1 issues chunk k - 1 + NB)
+    constexpr int last = c == 0 ? NB - 1 : (c - 2 + NB < NXC - 1 ? c - 2 + NB : NXC - 1);
+    constexpr int younger = (last > c ? last - c : 0) * PPW;
+    wait_vmcnt<younger>();
+    __builtin_amdgcn_s_barrier();
+    if constexpr (c == 1) RU_STAMP(1);
+    if constexpr (c >= 1 && c - 1 + NB < NXC) {
+      issue_x(std::integral_constant<int, c - 1 + NB>{});
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("" ::: "memory");
+#endif
+    }
+    static_for<PIECES>([&](auto pc) {
+      constexpr int pcs = decltype(pc)::value;
+      // halo row of pixel row 16 p + c16: (16 p + c16) / 22 takes one of two values inside a piece; the swizzle needs its parity
+      const int hy = (pcs * 16 + c16) / kHW;
+      const bf16x8 xb = *reinterpret_cast<const bf16x8*>(smem + (c % NB) * IMG_B + pcs * 1024 + rA + ((q ^ ((hy & 1) << 1)) << 4));
+      static_for<NFA>([&](auto fc) {
+        constexpr int fa = decltype(fc)::value;
+        f32x4& t = acc1[pcs][fa];
+        const bf16x8 &wa = w1f[fa][c], &xbr = xb;            // (bound here: asm operands alone do not capture in a lambda)
+        (void)t, (void)wa, (void)xbr;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // (c == 0: the accumulator starts as this MFMA's result, C operand = the inline constant 0 - never a v_mov next to the asm
+        // MFMAs: hipcc does not see through them and may place such a write into a register an MFMA issued just before still reads)
+        if constexpr (c == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(t) : "v"(wa), "v"(xbr));
+        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(t) : "v"(wa), "v"(xbr));
+#endif
+      });
+    });
+  });
+  RU_STAMP(2);
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_nop 15\n\ts_nop 15");                  // the asm MFMAs' D registers: wait states before any other reader
+  static_for<NFA>([&](auto fc) {                           // (W1 stays live until here: nothing may reuse its registers next to the MFMAs)
+    static_for<NXC>([&](auto kc) {
+      const bf16x8& wa = w1f[decltype(fc)::value][decltype(kc)::value];
+      asm volatile("" ::"v"(wa));
+    });
+  });
+#endif
+  wait_lds();
+  __builtin_amdgcn_s_barrier();                            // everybody is done with the last x chunks: the buffers take t now
+  static_for<PIECES>([&](auto pc) {
+    constexpr int pcs = decltype(pc)::value;
+    const int row = pcs * 16 + c16;
+    const int hy = row / kHW, hx = row - hy * kHW;
+    const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+    const bool inimg = row < G::HP && (unsigned)yy < (unsigned)d.h && (unsigned)xx < (unsigned)d.w;
+    static_for<NFA>([&](auto fc) {
+      constexpr int fa = decltype(fc)::value;
+      f32x4 v = act4(acc1[pcs][fa] + b1v[fa]);
+      if (!inimg) v = f32x4{0.f, 0.f, 0.f, 0.f};           // the 3x3 zero-pads t, not x
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (bf16_t)v[e];
+      // t channels f * 16 + q * 4 + e with f = wave * NFA + fa: image f / 2, 8-channel group (f & 1) * 2 + (q >> 1), second
+      // half of the slot for odd q
+      const int f = wave * NFA + fa;
+      *reinterpret_cast<bf16x4*>(smem + (f >> 1) * IMG_B + row * 64 + ((((f & 1) * 2 + (q >> 1)) ^ ((hy & 1) << 1)) << 4) + (q & 1) * 8) = o;
+    });
+  });
+
+  // W2 fragments of the first two steps: they land under phase A's epilogue
+  const uint32_t wv = (uint32_t)(((wave * (NFW * 16) + c16) * d.kpad + q * 8) * 2);
+  const uint32_t wfrag = (uint32_t)(16 * d.kpad * 2);
+  auto wload = [&](int c, int tap, int i) -> bf16x8 {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rw, wv + i * wfrag, (uint32_t)((tap * CMID + c * 32) * 2), 0));
+  };
+  bf16x8 wf[3][NFW];
+#pragma unroll
+  for (int i = 0; i < NFW; ++i) {
+    wf[0][i] = wload(0, 0, i);
+    wf[1][i] = wload(0, 1, i);
+  }
+
+  wait_lds();
+  __builtin_amdgcn_s_barrier();                            // the image buffers now hold the whole intermediate halo
+  RU_STAMP(3);
+
+  if (a.debug & 1024) {                                    // diagnosis: block 0 dumps its t images into y, nobody computes
+    if (blockIdx.x == 0)
+      for (int i = tid; i < G::LDS_B / 16; i += 256) reinterpret_cast<u32x4*>(a.y)[i] = reinterpret_cast<const u32x4*>(smem)[i];
+    return;
+  }
+
+  // ---- phase B
+  const int dy = c16 >> 2, dx = c16 & 3;
+  uint32_t A[2];                                           // halo bases by parity of (dy + tap row)
+#pragma unroll
+  for (int par = 0; par < 2; ++par) A[par] = (uint32_t)((dy * kHW + dx) * 64 + ((q ^ (((dy + par) & 1) << 1)) << 4));
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(A[0]), "+v"(A[1]));
+#endif
+  auto xread = [&](int jj, int tap, uint32_t am) -> bf16x8 {
+    const char* const p = smem + am;
+    return *reinterpret_cast<const bf16x8*>(p + ((4 * (jj / 5)) * kHW + 4 * (jj % 5)) * 64 + ((tap / 3) * kHW + tap % 3) * 64);
+  };
+  f32x4 acc[NFW][NP];
+#pragma unroll
+  for (int i = 0; i < NFW; ++i)
+#pragma unroll
+    for (int j = 0; j < NP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 xf[XD];
+  for (int c = 0; c < NIMG; ++c) {
+    static_for<9>([&](auto tc) {
+      constexpr int tap = decltype(tc)::value;
+      constexpr int par = (tap / 3) & 1, par_n = (((tap + 1) % 9) / 3) & 1;
+      {
+        constexpr int t2 = (tap + 2) % 9;
+        const int c2 = c + (tap + 2) / 9;                  // (beyond the last chunk: in-bounds rows of W2's k padding or zeros, never used)
+#pragma unroll
+        for (int i = 0; i < NFW; ++i) wf[(tap + 2) % 3][i] = wload(c2, t2, i);
+      }
+      const uint32_t am = A[par];
+      const uint32_t am_n = tap == 8 ? A[par_n] + (uint32_t)IMG_B : A[par_n];
+      if constexpr (tap == 0) {
+        if (c == 0) {
+#pragma unroll
+          for (int j = 0; j < XD - 1; ++j) xf[j] = xread(j, 0, am);
+        }
+      }
+      static_for<NP>([&](auto jc) {
+        constexpr int jj = decltype(jc)::value;
+        // rotation: patch jj of tap t lives in xf[(jj + t * NP) % XD]; NP % XD == 1 (25, 10), so the slot of the next tap's patch j is
+        // the slot "patch NP + j of this tap" would take
+        constexpr int R = (tap * NP) % XD;
+        static_assert(NP % XD == 1, "rotation");
+        if constexpr (jj + XD - 1 < NP) xf[(jj + XD - 1 + R) % XD] = xread(jj + XD - 1, tap, am);
+        else if constexpr (tap < 8) xf[(jj + XD - 1 + R) % XD] = xread(jj + XD - 1 - NP, tap + 1, am_n);   // the next step's first ones
+        else if (c + 1 < NIMG) xf[(jj + XD - 1 + R) % XD] = xread(jj + XD - 1 - NP, 0, am_n);               // ... in the next image
+        static_for<NFW>([&](auto ic) { mfma(acc[decltype(ic)::value][jj], wf[tap % 3][decltype(ic)::value], xf[(jj + R) % XD]); });
+      });
+    });
+    A[0] += (uint32_t)IMG_B;
+    A[1] += (uint32_t)IMG_B;
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_nop 15\n\ts_nop 15");
+#endif
+  RU_STAMP(4);
+#ifdef YOLO_STAMPS
+  if (a.stamps && tid == 0) a.stamps[8 * (size_t)blockIdx.x + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+#endif
+  if (a.debug & 8) return;
+  __syncthreads();                                         // every wave is done with t: the staging slabs reuse the image buffers
+
+  // ---- epilogue
+  constexpr int CT = G::CT, U = G::U, PITCH = G::PITCH, SLAB = G::SLAB;
+  constexpr int LPR = CT / 8, RPW = 64 / LPR;              // lanes per pixel row (8 couts each), rows per wave and pass
+  constexpr int NUNIT = (NP + U - 1) / U;
+  f32x4 b2v[NFW];
+#pragma unroll
+  for (int i = 0; i < NFW; ++i) b2v[i] = *reinterpret_cast<const f32x4*>(a.bias + wave * (NFW * 16) + i * 16 + q * 4);
+  const uint32_t y_pitch = (uint32_t)d.out_c_total * 2u, r_pitch = (uint32_t)d.res_c_total * 2u, x_pitch = (uint32_t)d.aux_c_total * 2u;
+  const uint32_t npix = (uint32_t)d.n * d.h * d.w;
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, npix * y_pitch, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, npix * r_pitch, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rax = __builtin_amdgcn_make_buffer_rsrc((void*)a.aux, 0, a.aux ? npix * x_pitch : 0u, 0x00020000);
+  // pass ps of a unit covers slab rows ps * 8 U + wave * RPW + lane / LPR: patch u = row / 16, patch pixel row % 16
+  const int cch = lane % LPR;
+  uint32_t yo[2], ro[2], ao[2];
+  int ylim[2], xlim[2], srow[2];
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    srow[ps] = ps * 8 * U + wave * RPW + lane / LPR;
+    const int r16 = srow[ps] & 15;
+    const int dyr = r16 >> 2, dxr = r16 & 3;
+    const uint32_t lpix = (uint32_t)((b * d.h + y0 + dyr) * d.w + x0 + dxr);
+    const uint32_t ccol = (uint32_t)(cch * 8) * 2u;
+    yo[ps] = lpix * y_pitch + (uint32_t)d.out_c_offset * 2u + ccol;
+    ro[ps] = lpix * r_pitch + (uint32_t)d.res_c_offset * 2u + ccol;
+    ao[ps] = lpix * x_pitch + (uint32_t)d.aux_c_offset * 2u + ccol;
+    ylim[ps] = d.h - y0 - dyr;
+    xlim[ps] = d.w - x0 - dxr;
+  }
+  auto voff = [&](uint32_t base, uint32_t pitch, int ps, int jj) -> uint32_t {
+    const int pr = jj / 5, pc = jj % 5;
+    const bool ok = jj < NP && 4 * pr < ylim[ps] && 4 * pc < xlim[ps];
+    return ok ? base + (uint32_t)(4 * pr * d.w + 4 * pc) * pitch : kOobOffset;
+  };
+  u32x4 rv[RD + 1][2];
+  auto fetch_res = [&](auto pc_) {
+    constexpr int pi = decltype(pc_)::value;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps)                         // (U == 2: pass ps is patch U pi + ps; U == 1: both passes are patch pi)
+      rv[pi % (RD + 1)][ps] = __builtin_amdgcn_raw_buffer_load_b128(rr, voff(ro[ps], r_pitch, ps, U * pi + (U == 2 ? ps : 0)), 0, 0);
+  };
+  static_for<(RD < NUNIT ? RD : NUNIT)>([&](auto kc) { fetch_res(kc); });
+  static_for<NUNIT>([&](auto pc_) {
+    constexpr int pi = decltype(pc_)::value;
+    char* const slab = smem + (pi & 1) * SLAB;
+    static_for<U>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      if constexpr (U * pi + u < NP) {
+        static_for<NFW>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          *reinterpret_cast<f32x4*>(slab + (u * 16 + c16) * PITCH + (wave * (NFW * 16) + i * 16 + q * 4) * 4) = act4(acc[i][U * pi + u] + b2v[i]);
+        });
+      }
+    });
+    if constexpr (pi + RD < NUNIT) fetch_res(std::integral_constant<int, pi + RD>{});
+    wait_lds();
+    __builtin_amdgcn_s_barrier();                          // the unit is staged by all four waves (and unit pi - 1 has been read by all)
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int jj = U * pi + (U == 2 ? ps : 0);
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(slab + srow[ps] * PITCH + cch * 32);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(slab + srow[ps] * PITCH + cch * 32 + 16);
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      if (a.aux) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rax, voff(ao[ps], x_pitch, ps, jj), 0, 0);
+      }
+      const bf16x8 r8 = __builtin_bit_cast(bf16x8, rv[pi % (RD + 1)][ps]);
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(v[e] + (float)r8[e]);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, voff(yo[ps], y_pitch, ps, jj), 0, 0);
+    }
+  });
+#ifdef YOLO_STAMPS
+  wait_vmcnt<0>();                                         // (the stores have left: the diagnostic build times the whole epilogue)
+#endif
+  RU_STAMP(5);
+}
+
+template <int CMID, int TPH>
+int launch_ruw(const RU20Args& ra, bool force, hipStream_t s) {
+  const YoloConvDesc& d = ra.c.d;
+  const long tiles = (long)d.n * ((d.h + 4 * TPH - 1) / (4 * TPH)) * ((d.w + kT - 1) / kT);
+  // partial tiles idle lanes (and MFMAs); few tiles leave CUs without their two workgroups
+  if (!force && ((double)d.n * d.h * d.w < 0.9 * (80.0 * TPH) * tiles || tiles < 512)) return 1;
+  if (tiles > 0x7fffffffL) return 1;
+  if (pick_only("resunit_t20w<C %d, %dpx x %d couts, 4 waves> grid %ld", 2 * CMID, 80 * TPH, 2 * CMID, tiles)) return 0;
+  hipLaunchKernelGGL((resunit_t20w_kernel<CMID, TPH>), dim3((unsigned)tiles), dim3(256), (ra.c.debug & 512) ? 40 * 1024 : 0, s, ra);   // bit 512: one workgroup per CU (diagnosis)
+  return yolo_check_launch("yolo_resunit_fwd(t20w)");
+}
+
 }  // namespace
 
 namespace yolo_conv {
 
 // 1: not this kernel's case (the caller falls back to the 16x16-tile kernels)
-int launch_resunit64_t20(const ConvArgs& c, const bf16_t* w1, const float* b1, int kpad1, uint32_t w1_bytes, bool force, hipStream_t s) {
+int launch_resunit_t20(const ConvArgs& c, const bf16_t* w1, const float* b1, int kpad1, uint32_t w1_bytes, bool force, hipStream_t s) {
   const YoloConvDesc& d = c.d;
-  if (d.cout != 64 || d.cin != 32 || d.act == YOLO_ACT_SWISH || !c.res) return 1;
-  const long tiles = (long)d.n * ((d.h + kT - 1) / kT) * ((d.w + kT - 1) / kT);
-  // partial tiles idle lanes; few tiles: the persistent 16x16-tile kernel (YOLO_RESUNIT_DEBUG bit 64 forces this one)
-  if (!force && ((double)d.n * d.h * d.w < 0.9 * 400.0 * tiles || tiles < 256)) return 1;
+  if (d.cin * 2 != d.cout || d.act == YOLO_ACT_SWISH || !c.res) return 1;
+  if (d.cout != 64 && d.cout != 128 && d.cout != 256) return 1;
   const size_t npix = (size_t)d.n * d.h * d.w;
   if (npix * d.out_c_total * 2 >= kOobOffset || npix * d.res_c_total * 2 >= kOobOffset || (c.aux && npix * d.aux_c_total * 2 >= kOobOffset))
     return 1;
-  if (tiles > 0x7fffffffL) return 1;
-  if (pick_only("resunit64_t20<400px x 64 couts, 4 waves> grid %ld", tiles)) return 0;
   RU20Args ra;
   ra.c = c;
   ra.w1 = w1;
   ra.b1 = b1;
   ra.kpad1 = kpad1;
   ra.w1_bytes = w1_bytes;
+  YOLO_SET_STAMPS(ra.c);
+  static const int stagger_env = getenv("YOLO_RESUNIT_STAGGER") ? atoi(getenv("YOLO_RESUNIT_STAGGER")) : -1;   // tuning only
+  ra.stagger = stagger_env >= 0 ? stagger_env : 0;
+  if (d.cout == 128) return launch_ruw<64, 5>(ra, force, s);
+  if (d.cout == 256) return launch_ruw<128, 2>(ra, force, s);
+  const long tiles = (long)d.n * ((d.h + kT - 1) / kT) * ((d.w + kT - 1) / kT);
+  // partial tiles idle lanes; few tiles: the persistent 16x16-tile kernel (YOLO_RESUNIT_DEBUG bit 64 forces this one)
+  if (!force && ((double)d.n * d.h * d.w < 0.9 * 400.0 * tiles || tiles < 256)) return 1;
+  if (tiles > 0x7fffffffL) return 1;
+  if (pick_only("resunit64_t20<400px x 64 couts, 4 waves> grid %ld", tiles)) return 0;
   hipLaunchKernelGGL(resunit64_t20_kernel, dim3((unsigned)tiles), dim3(256), 0, s, ra);
   return yolo_check_launch("yolo_resunit_fwd(t20)");
 }

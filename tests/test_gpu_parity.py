@@ -192,7 +192,11 @@ def test_conv_tile_configurations(case):
                                               (2, 80, 112, 256, True), (3, 96, 160, 64, True), (16, 320, 320, 64, False),
                                               # >= 256 tiles of 20x20 covering >= 90 % of the map: conv_resunit_t20.hip (whole tiles
                                               # with the pre-add copy; partial edge tiles in both directions)
-                                              (3, 200, 200, 64, True), (3, 190, 230, 64, True), (4, 163, 178, 64, False)])
+                                              (3, 200, 200, 64, True), (3, 190, 230, 64, True), (4, 163, 178, 64, False),
+                                              # round 3, resunit_t20w_kernel: C = 128 on >= 512 tiles of 20x20, C = 256 on >= 512
+                                              # tiles of 20x8 (whole tiles; partial edge tiles in both directions + pre-add copy)
+                                              (2, 320, 320, 128, False), (3, 290, 310, 128, True),
+                                              (4, 160, 160, 256, True), (5, 150, 170, 256, False)])
 def test_fused_residual_unit(n, h, w, c, use_aux):
     """yolo_resunit_fwd (1x1 -> 3x3 -> add in one launch) against fp32 torch on the same bf16-rounded operands
     (the 1x1 output rounded to bf16 like the stored intermediate of the two-kernel path), and against the
