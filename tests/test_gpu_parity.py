@@ -1682,6 +1682,73 @@ def test_t20_conv_kernel(case):
     assert float((diff > 0).float().mean()) < 0.25   # same operands, another fp32 summation order: a minority of last-bit flips
 
 
+T20S2_CASES = [
+    # n, h, w (input), cin, cout, use_aux: stride-2 3x3 on 20x20 output tiles, four parity planes per 32-channel chunk (round 3)
+    (2, 80, 80, 64, 128, False),          # whole tiles, two chunks (the 320 -> 160 layer's shape class)
+    (1, 40, 40, 256, 512, True),          # one tile per image, eight chunks, four cout tiles, pre-add copy
+    (3, 75, 83, 96, 256, True),           # odd input sizes: outputs 38 x 42, partial tiles on both edges, three chunks
+    (2, 41, 40, 32, 128, False),          # one chunk: prologue and the dummy plane only; odd height (the last input row is used)
+    (1, 160, 160, 128, 256, False),       # 16 tiles per image
+]
+
+
+@pytest.mark.parametrize("case", T20S2_CASES, ids=lambda c: "n%d_%dx%d_c%d-%d_a%d" % tuple(int(v) for v in c))
+def test_t20_stride2_conv_kernel(case):
+    """conv3x3s2_t20_kernel (reference DownSample.conv0, models/yolov3_spp.py:26-27: 3x3 / stride 2 / pad 1 + BN + LeakyReLU) forced
+    onto every shape class: against fp32 torch on the same bf16-rounded operands, untouched channels of the output views intact,
+    and within fp32 summation-order noise of the gather kernel's result."""
+    from pytorch_yolo_amd import kernels as K
+    from pytorch_yolo_amd._lib import ACT_LEAKY01, load
+    n, h, w, cin, cout, use_aux = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    in_ct, in_co = cin + 16, 8
+    xin = torch.zeros(n, h, w, in_ct, dtype=torch.bfloat16, device=DEV)
+    xin[..., in_co:in_co + cin] = _nhwc(x)
+    out_ct, out_co = cout + 8, 8
+    wp, bp, kpad, cout_pad = K.pack_conv_weight(wt, bias, cin)
+    d = K.conv_desc(n=n, h=h, w=w, cin=cin, in_c_total=in_ct, in_c_offset=in_co, cout=cout, out_c_total=out_ct,
+                    out_c_offset=out_co, ksize=3, stride=2, act=ACT_LEAKY01, kpad=kpad, cout_pad=cout_pad,
+                    aux=(cout + 8, 8) if use_aux else (0, 0))
+    assert (d.ho, d.wo) == (ho, wo)
+    outs = {}
+    lib = load()
+    old = lib.yolo_set_tuning(2, 0)
+    try:
+        for arm in (64, 16):                        # 64: the 20x20-tile kernels never (the gather kernel's result); 16: always
+            lib.yolo_set_tuning(2, arm)
+            assert ("t20s2" in K.conv2d_pick(d, False, use_aux)) == (arm == 16)
+            y = torch.full((n, ho, wo, out_ct), -77.0, dtype=torch.bfloat16, device=DEV)
+            aux = torch.full((n, ho, wo, cout + 8), -77.0, dtype=torch.bfloat16, device=DEV) if use_aux else None
+            K.conv2d(xin, wp.to(DEV), bp.to(DEV), y, d, y_preadd=aux)
+            torch.cuda.synchronize()
+            outs[arm] = (y, aux)
+    finally:
+        lib.yolo_set_tuning(2, old)
+    ref = F.leaky_relu(F.conv2d(_bf16r(x), _bf16r(wt), bias, stride=2, padding=1), 0.1)
+    y, aux = outs[16]
+    torch.testing.assert_close(_nchw(y[..., out_co:out_co + cout]), ref, rtol=1e-2, atol=1e-2)
+    assert torch.all(y[..., :out_co] == -77.0)
+    if use_aux:
+        torch.testing.assert_close(_nchw(aux[..., 8:8 + cout]), ref, rtol=1e-2, atol=1e-2)
+        assert torch.all(aux[..., :8] == -77.0)
+    y0 = outs[64][0]
+    diff = (y.float() - y0.float()).abs()
+    assert float(diff.max()) <= 2 ** -6 * max(1.0, float(y0.float().abs().max())), "differs from the gather kernel by more than 2 bf16 ulp"
+    assert float((diff > 0).float().mean()) < 0.25
+    y2 = torch.full_like(y, -77.0)                   # run to run identical (a race between the plane buffers would show here)
+    lib.yolo_set_tuning(2, 16)
+    try:
+        K.conv2d(xin, wp.to(DEV), bp.to(DEV), y2, d, y_preadd=aux)
+        torch.cuda.synchronize()
+    finally:
+        lib.yolo_set_tuning(2, old)
+    assert torch.equal(y, y2)
+
+
 # ------------------------------------------------------------------------------------------------
 # EfficientNet-B0 encoder (SURVEY 8f rank 4, third of three): swish, depthwise 3x3 / 5x5 with TensorFlow "same" padding,
 # squeeze-and-excitation.  torch is the reference for the kernels; the encoder oracle restates the published architecture

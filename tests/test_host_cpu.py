@@ -350,8 +350,8 @@ def test_tile_rules_pick_the_intended_kernels():
         (16, 80, 80, 128, 256, 3, 1, True): t20 % 512,
         (16, 40, 40, 256, 512, 3, 1, True): t20 % 256,
         (16, 20, 20, 512, 1024, 3, 1, True): t20 % 128,
-        # stride-2 downsamples: implicit GEMM
-        (16, 160, 160, 128, 256, 3, 2): "igemm<256x256,4x4 waves,BK64,2 stages,16x16x32> grid 400",
+        # stride-2 downsamples: the parity-plane form of the 20x20-tile kernel where it gets two workgroups per CU, else implicit GEMM
+        (16, 160, 160, 128, 256, 3, 2): "t20s2<400px x 128 couts, 4 waves, parity planes> grid 512",
         (16, 80, 80, 256, 512, 3, 2): "igemm<256x256,4x4 waves,BK64,2 stages,16x16x32> grid 200",
         (16, 40, 40, 512, 1024, 3, 2): "igemm<128x256,2x4 waves+4 loaders,BK64,3 stages,16x16x32> grid 200",
         # memory-bound 1x1 bottlenecks at the two big maps: weight-stationary streaming kernel
@@ -365,6 +365,27 @@ def test_tile_rules_pick_the_intended_kernels():
     }
     got = {k: _pick(*k) for k in expect}
     assert got == expect
+    # the whole-batch launch lists of bench.py (32 images per pipeline): what the headline number actually runs
+    s2 = "t20s2<400px x 128 couts, 4 waves, parity planes> grid %d"
+    expect32 = {
+        (32, 160, 160, 64, 128, 3, 1, True): t20 % 2048,
+        (32, 80, 80, 128, 256, 3, 1, True): t20 % 1024,
+        (32, 80, 80, 256, 256, 3, 1): t20 % 1024,
+        (32, 40, 40, 256, 512, 3, 1, True): t20 % 512,
+        (32, 20, 20, 512, 1024, 3, 1, True): t20 % 256,
+        (32, 320, 320, 64, 128, 3, 2): s2 % 2048,
+        (32, 160, 160, 128, 256, 3, 2): s2 % 1024,
+        (32, 80, 80, 256, 512, 3, 2): s2 % 512,
+        (32, 40, 40, 512, 1024, 3, 2): "igemm<256x256,4x4 waves,BK64,2 stages,16x16x32> grid 200",     # 256 workgroups of 20x20: one per CU
+        (32, 160, 160, 128, 64, 1, 1): "stream1x1<64 couts,K 128> grid 512",
+        (32, 80, 80, 256, 128, 1, 1): "stream1x1<128 couts,K 256> grid 512",
+        # (M = 51,200 >= 40,000 puts this layer under the "short-K 1x1 on a big map" rule at 32 images; measured there: 0.0256 ms,
+        # 128x256 / 3 stages 0.0261, 256x256 0.0234 - profiles/r03_1x1_variants_n32.txt)
+        (32, 40, 40, 512, 256, 1, 1): "igemm<256x128,4x2 waves,BK32,2 stages,16x16x32> grid 400",
+        (32, 20, 20, 1024, 512, 1, 1): "igemm<128x256,2x8 waves,BK64,3 stages,16x16x32> grid 200",
+    }
+    got32 = {k: _pick(*k) for k in expect32}
+    assert got32 == expect32, {k: v for k, v in got32.items() if expect32[k] != v}
     # 13x13 maps (416 input) do not tile by 20: never the t20 kernel
     assert _pick(32, 13, 13, 512, 1024, 3, 1).startswith("igemm<")
     # a bad descriptor is still rejected in pick mode
@@ -386,7 +407,7 @@ def test_tile_rules_follow_the_cu_share_of_a_partitioned_stream():
         assert _pick(16, 20, 20, 1024, 512, 1, 1) == "igemm<128x256,2x8 waves,BK64,3 stages,16x16x32> grid 100"
         assert _pick(16, 40, 40, 512, 256, 1, 1) == "igemm<256x256,4x4 waves,BK64,2 stages,16x16x32> grid 100"
         assert _pick(16, 40, 40, 512, 1024, 3, 2) == "igemm<256x256,4x4 waves,BK64,2 stages,16x16x32> grid 100"
-        assert _pick(16, 160, 160, 128, 256, 3, 2) == "igemm<128x128,2x4 waves,BK64,2 stages,16x16x32> grid 1600"
+        assert _pick(16, 160, 160, 128, 256, 3, 2) == "t20s2<400px x 128 couts, 4 waves, parity planes> grid 512"     # 4 per CU of the share
         assert _pick(16, 20, 20, 512, 1024, 3, 1, True) == "t20v2<400px x 128 couts, 4 waves> grid 128"
         assert _pick(16, 80, 80, 256, 128, 1, 1) == "stream1x1<128 couts,K 256> grid 512"
     finally:
