@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void resunit_t20w_kernel(const RU20Args ra)
   using G = RUW<CMID, TPH>;
   constexpr int PPW = G::PPW, IMG_B = G::IMG_B, NIMG = G::NIMG, NXC = G::NXC, NFW = G::NFW, NP = G::NP;
   constexpr int NB = NIMG;                               // x staging buffers = the t images
-  constexpr int RD = 3, XD = 3;
+  constexpr int RD = CMID == 64 ? 2 : 3, XD = 3;         // (25 patches x 2 fragments: 200 accumulator registers leave room for two units of residual rows in flight)
   __shared__ __attribute__((aligned(16))) char smem[G::LDS_B];
   const ConvArgs& a = ra.c;
   const YoloConvDesc& d = a.d;
@@ -404,8 +404,23 @@ __global__ __launch_bounds__(256, 2) void resunit_t20w_kernel(const RU20Args ra)
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("" ::: "memory");
 #endif
-  // fragment address of piece p in a buffer: pixel row 16 p + c16, k group q (slot = q ^ 2 * (halo row & 1))
-  const uint32_t rA = (uint32_t)(c16 * 64);
+  // Fragment address of piece p in a buffer: pixel row 16 p + c16, k group q, slot = q ^ 2 * (halo row & 1) - computed HERE, once,
+  // and kept in registers: inside the chunk loop nothing but ds_read, MFMA and waits may run.  hipcc does not see through the asm
+  // MFMAs, and a VALU result placed in a register that the MFMA issued just before still reads as its B operand (the fragment of
+  // the piece before, dead by then for the allocator) corrupts that MFMA - seen as run-to-run differing outputs with the address
+  // arithmetic inside the loop.  For the same reason a fragment register stays live (empty asm use) past the next piece's MFMAs.
+  uint32_t xaddr[PIECES];
+#pragma unroll
+  for (int pcs = 0; pcs < PIECES; ++pcs) {
+    const int hy = (pcs * 16 + c16) / kHW;
+    xaddr[pcs] = (uint32_t)(pcs * 1024 + c16 * 64 + ((q ^ ((hy & 1) << 1)) << 4));
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+  static_for<PIECES>([&](auto pc) {
+    uint32_t& t = xaddr[decltype(pc)::value];
+    asm volatile("" : "+v"(t));                            // opaque: never rematerialised inside the loop
+  });
+#endif
   f32x4 acc1[PIECES][NFA];
   static_for<NXC>([&](auto cc) {
     constexpr int c = decltype(cc)::value;
@@ -421,24 +436,41 @@ __global__ __launch_bounds__(256, 2) void resunit_t20w_kernel(const RU20Args ra)
       asm volatile("" ::: "memory");
 #endif
     }
+    bf16x8 xb[3];                                          // fragments in flight: piece p + 2 is requested before piece p is multiplied
+    auto xld = [&](auto pc) {
+      constexpr int pcs = decltype(pc)::value;
+      const char* const ptr = smem + xaddr[pcs];
+      xb[pcs % 3] = *reinterpret_cast<const bf16x8*>(ptr + (c % NB) * IMG_B);
+    };
+    xld(std::integral_constant<int, 0>{});
+    if constexpr (PIECES > 1) xld(std::integral_constant<int, 1>{});
     static_for<PIECES>([&](auto pc) {
       constexpr int pcs = decltype(pc)::value;
-      // halo row of pixel row 16 p + c16: (16 p + c16) / 22 takes one of two values inside a piece; the swizzle needs its parity
-      const int hy = (pcs * 16 + c16) / kHW;
-      const bf16x8 xb = *reinterpret_cast<const bf16x8*>(smem + (c % NB) * IMG_B + pcs * 1024 + rA + ((q ^ ((hy & 1) << 1)) << 4));
+      if constexpr (pcs + 2 < PIECES) xld(std::integral_constant<int, pcs + 2>{});
       static_for<NFA>([&](auto fc) {
         constexpr int fa = decltype(fc)::value;
         f32x4& t = acc1[pcs][fa];
-        const bf16x8 &wa = w1f[fa][c], &xbr = xb;            // (bound here: asm operands alone do not capture in a lambda)
+        const bf16x8 &wa = w1f[fa][c], &xbr = xb[pcs % 3];      // (bound here: asm operands alone do not capture in a lambda)
         (void)t, (void)wa, (void)xbr;
 #if defined(__HIP_DEVICE_COMPILE__)
-        // (c == 0: the accumulator starts as this MFMA's result, C operand = the inline constant 0 - never a v_mov next to the asm
-        // MFMAs: hipcc does not see through them and may place such a write into a register an MFMA issued just before still reads)
+        // (c == 0: the accumulator starts as this MFMA's result, C operand = the inline constant 0 - never a v_mov next to the asm MFMAs)
         if constexpr (c == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(t) : "v"(wa), "v"(xbr));
         else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(t) : "v"(wa), "v"(xbr));
 #endif
       });
+#if defined(__HIP_DEVICE_COMPILE__)
+      if constexpr (pcs >= 1) {
+        const bf16x8& prev = xb[(pcs - 1) % 3];
+        asm volatile("" ::"v"(prev));
+      }
+#endif
     });
+#if defined(__HIP_DEVICE_COMPILE__)
+    {
+      const bf16x8& lastf = xb[(PIECES - 1) % 3];
+      asm volatile("s_nop 7" ::"v"(lastf));                // the chunk's last MFMAs have read their operands before anything else runs
+    }
+#endif
   });
   RU_STAMP(2);
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -32,8 +32,9 @@ from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SWISH, DT_BF1
                    OP_STEM, YoloOp)
 
 # which residual-unit widths run as ONE launch (bit mask of C: 64 | 128 | 256); see DESIGN.md §3.1d for the
-# measurements behind the default.  YOLO_FUSE_RESUNIT overrides it (tuning only).
-FUSE_RESUNIT_DEFAULT = 64
+# measurements behind the default (round 3, three interleaved rounds on one box, images/s: 64 -> 6,180; 64 | 128 -> 6,222;
+# 64 | 128 | 256 -> 6,022: profiles/r03_fuse_resunit_ab.txt).  YOLO_FUSE_RESUNIT overrides it (tuning only).
+FUSE_RESUNIT_DEFAULT = 64 | 128
 
 
 # ------------------------------------------------------------------------------------------------

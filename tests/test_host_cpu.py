@@ -119,12 +119,14 @@ def test_planner_spp_fusions():
     # the stem (conv1 + the stride-2 conv) reads the NCHW f32 batch itself and is ONE launch (yolo_stem_fwd)
     assert ops[0].kind == OP_STEM and plan.fused_input and kinds.count(OP_STEM) == 1
     assert (ops[0].conv.h, ops[0].conv.ho, ops[0].conv.cout, ops[0].conv.res_c_total) == (640, 320, 64, 3)
-    # no add / cat / upsample / pack launches; the 64-channel residual unit at 320^2 is ONE launch (yolo_resunit_fwd)
-    assert kinds.count(OP_CONV) == 69 and kinds.count(OP_RESUNIT) == 1 and kinds.count(OP_SPP) == 1 and len(ops) == 75
-    unit = ops[kinds.index(OP_RESUNIT)]
-    assert (unit.conv.cout, unit.conv.cin, unit.conv.h) == (64, 32, 320) and unit.y != unit.x and unit.w_pre and unit.bias_pre
+    # no add / cat / upsample / pack launches; the 64-channel residual unit at 320^2 and the two 128-channel units at 160^2 are
+    # ONE launch each (yolo_resunit_fwd; round 3: engine.FUSE_RESUNIT_DEFAULT = 64 | 128)
+    assert kinds.count(OP_CONV) == 65 and kinds.count(OP_RESUNIT) == 3 and kinds.count(OP_SPP) == 1 and len(ops) == 73
+    units = [o for o in ops if o.kind == OP_RESUNIT]
+    assert [(u.conv.cout, u.conv.cin, u.conv.h) for u in units] == [(64, 32, 320), (128, 64, 160), (128, 64, 160)]
+    assert all(u.y != u.x and u.w_pre and u.bias_pre for u in units)
     convs = [o for o in ops if o.kind == OP_CONV]
-    assert sum(1 for o in convs if o.residual) == 22                                        # every other Add is an epilogue
+    assert sum(1 for o in convs if o.residual) == 20                                        # every other Add is an epilogue
     assert all(o.residual == o.y for o in convs if o.residual)                              # ... written in place
     aux = [o for o in convs if o.y_aux]
     assert [(o.conv.aux_c_total, o.conv.aux_c_offset) for o in aux] == [(384, 128), (768, 256)]   # pre-add routes -> concat slices
