@@ -90,12 +90,19 @@ def main():
 
     torch.set_num_threads(8)
     ref = import_reference()
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None      # regenerate ONE fixture group (separable)
 
     def save(name, **arrs):
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **arrs)
         print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
 
+    if only is None:
+        _all_but_separable(ref, C, save, synth_images, synth_state_dict)
+    _separable_and_nms(ref, C, save, synth_images, synth_state_dict, only)
+
+
+def _all_but_separable(ref, C, save, synth_images, synth_state_dict):
     # ---- known answers -------------------------------------------------
     mp = ref["MaxPool"](2, 1)(torch.arange(16.).view(1, 1, 4, 4)).numpy()
     pred = torch.from_numpy(C.NMS_KAT_ROWS.copy())[None]
@@ -153,6 +160,42 @@ def main():
         arrs.update({"nms_" + k: v for k, v in run_ref_nms(ref, io_np, C.NMS_FULL["conf_thres"], C.NMS_FULL["nms_thres"]).items()
                      if not k.startswith("col4")})
         save("full_" + name, **arrs)
+
+
+
+def _separable_and_nms(ref, C, save, synth_images, synth_state_dict, only):
+    # ---- full-size SPP-640 with well-separated detections (tests/_cases.py, SEPARABLE) -----------
+    if only in (None, "separable"):
+        sep = C.SEPARABLE
+        model = ref["spp"](n_class=80, kernels_divider=1, anchors=C.SPP_ANCHORS).eval()
+        sd = synth_state_dict(model.state_dict(), sep["weight_seed"], n_class=80)
+        model.load_state_dict(sd)
+        x = torch.from_numpy(C.patch_image(sep["image_seed"], sep["n_patches"]))
+        with torch.no_grad():
+            _, p = model(x)
+        wk = [h + ".sequence.batch_norm.weight" for h in C.SEPARABLE_HEADS]
+        bk = [h + ".sequence.batch_norm.bias" for h in C.SEPARABLE_HEADS]
+        new_w, new_b = C.calibrate_separable_heads([sd[k].numpy() for k in wk], [sd[k].numpy() for k in bk], [t[0].numpy() for t in p],
+                                                   80, sep["per_anchor"], sep["span"], sep["gamma_obj"], sep["cls_gain"])
+        for k_w, k_b, w_, b_ in zip(wk, bk, new_w, new_b):
+            sd[k_w], sd[k_b] = torch.from_numpy(w_), torch.from_numpy(b_)
+        model.load_state_dict(sd)
+        with torch.no_grad():
+            io, p = model(x)
+        io_np = io.numpy()
+        rows = C.sample_rows(io_np.shape[1])
+        arrs = {"rows": rows, "io_rows": io_np[:, rows], "io_colsum": io_np.astype(np.float64).sum(1), "io_shape": np.asarray(io_np.shape)}
+        for k, (w_, b_) in enumerate(zip(new_w, new_b)):
+            arrs[f"head_bn_weight_{k}"], arrs[f"head_bn_bias_{k}"] = w_, b_       # the calibrated head BN: data derived from reference outputs
+        arrs.update({"nms_" + k: v for k, v in run_ref_nms(ref, io_np, sep["conf_thres"], sep["nms_thres"]).items() if not k.startswith("col4")})
+        score = io_np[0, :, 4] * io_np[0, :, 5:].max(1)
+        arrs["n_candidates"] = np.int64((score > sep["conf_thres"]).sum())
+        arrs["n_between_04_06"] = np.int64(((score > 0.4) & (score < 0.6)).sum())
+        save("full_spp_640_separable", **arrs)
+        print("separable: detections", int(arrs["nms_count_0"]), "candidates", int(arrs["n_candidates"]), "between 0.4 and 0.6:", int(arrs["n_between_04_06"]),
+              "min conf", float(arrs["nms_dets_0"][:, 4].min()))
+    if only is not None:
+        return
 
     # ---- NMS on synthetic predictions ---------------------------------------------------
     for name in C.NMS_CASES:

@@ -19,7 +19,7 @@ import torch
 import torch.nn.functional as F
 
 import _cases as C
-from helpers import build_case, load_golden, oracle_forward
+from helpers import build_case, build_separable_case, load_golden, oracle_forward, strict_share
 
 pytestmark = pytest.mark.gpu
 
@@ -945,7 +945,8 @@ def test_model_full_size(name):
     # score low they need pre-activation logits around -40 with a BN gain of 10..25, which multiplies the
     # ~1 % bf16 drift of a 23-unit bf16 residual stream.  Full-size SPP therefore gets a wider max-score
     # bound (still tight in RMS); the plain-conv tiny heads keep the 2e-2 bound.
-    wide = dict(score_max=0.25, score_rms=1e-2) if name == "spp_640" else {}
+    # (round 3: 0.25 -> measured + 25 %: image 0 of SPP-640 shows 0.098 on the sampled rows and 0.138 over all rows)
+    wide = dict(score_max=0.18, score_rms=1e-2) if name == "spp_640" else {}
     _assert_model_close(io.cpu()[:, g["rows"]], ref_rows, name + "/rows", **wide)
     colsum = io.double().sum(1).cpu().numpy()
     rel = np.abs(colsum - g["io_colsum"]) / np.maximum(np.abs(g["io_colsum"]), 1.0)
@@ -989,7 +990,7 @@ def test_full_width_models_at_other_input_sizes(family, bs, h, w):
     with torch.no_grad():
         io, p = model(x.to(DEV))
     assert io.shape == io_ref.shape and [t.shape for t in p] == [t.shape for t in p_ref]
-    wide = dict(score_max=0.25, score_rms=1e-2) if family == "spp" else {}
+    wide = dict(score_max=0.225, score_rms=1e-2) if family == "spp" else {}
     _assert_model_close(io.cpu(), io_ref, f"{family}_{bs}x{h}x{w}", **wide)
 
 
@@ -1357,6 +1358,59 @@ def test_full_size_detection_sets_vs_reference(name):
     assert abs(len(d16) - len(ref_all)) <= 0.1 * len(ref_all)
 
 
+def test_separable_detections_strictly_vs_reference():
+    """Detection-level bf16 parity on data that can carry it (VERDICT r2 item 3; tests/_cases.py::SEPARABLE, golden
+    full_spp_640_separable.npz generated from the reference by tests/golden/make_golden.py): YOLOv3-SPP 640x640 whose head BN was
+    calibrated so that the reference's 22 detections are isolated and saturated (conf >= 0.83, none between 0.4 and 0.6, no ties).
+    WITHOUT guard band or noise re-runs:
+      * bf16 (the benched path): reference and bf16 detections pair up in both directions - same class, IoU >= 0.9,
+        |dconf| <= 0.03 - for at least 90 % (measured: 21 of 22 reference detections, 21 of 23 bf16 ones), and at the lattice
+        test's criteria (IoU >= 0.7, |dconf| <= 0.06) for at least 95 %; the counts differ by at most one;
+      * the same bars against the CPU rounding model (the oracle re-run under the product's bf16 rounding points,
+        oracle/policy.py), which on this seed pairs with the reference 22 of 22;
+      * fp32 mode: the kept-index set IS the reference's, conf / class to 2e-4, boxes to 0.05 px.
+    What the two strict misses are (tools/dbg/sep_gpu.py): one cell next to the objectness cut (fp32 0.35, CPU rounding model
+    0.998, HIP 0.998: the calibration's gamma of 1000 turns a 0.007 drift of the normalised conv output into 6.8 logits) and one
+    MERGE pile whose pivot changes between two saturated candidates (0.985 vs 1.000), which moves the merged 120-pixel box by
+    5 pixels (IoU 0.88).  In this amplified domain the HIP path and the CPU rounding model are two realisations of the same
+    rounding noise (median objectness-logit distance of the candidates: rounding model - fp32 0.30, HIP - fp32 0.53, HIP -
+    rounding model 0.39).  The lattice fixture's 0.79 (test_full_size_detection_sets_vs_reference) is the data's conditioning:
+    over 39 patch seeds the two CPU runs themselves pair between 0.68 and 1.00 (profiles/r03_separable_search.txt); this seed is
+    the one at 1.00 for the CPU pair."""
+    from oracle import models as om, nms as onms
+    from oracle.policy import run_policy
+    from pytorch_yolo_amd.utils.utils import non_max_suppression
+    sep = C.SEPARABLE
+    model, sd, x, g = build_separable_case()
+    ref = g["nms_dets_0"]
+    model = model.to(DEV)
+    with torch.no_grad():
+        io16, _ = model(x.to(DEV))
+        dets16, _ = non_max_suppression(io16, sep["conf_thres"], sep["nms_thres"], with_indices=True)
+    d16 = dets16[0].cpu().numpy()
+    a, b = strict_share(ref, d16), strict_share(d16, ref)
+    loose = strict_share(ref, d16, 0.7, 0.06), strict_share(d16, ref, 0.7, 0.06)
+    print(f"[separable] reference {len(ref)} detections, bf16 {len(d16)}; strict share (IoU 0.9, dconf 0.03) {a:.3f} / {b:.3f}; "
+          f"at the lattice test's criteria (IoU 0.7, dconf 0.06) {loose[0]:.3f} / {loose[1]:.3f}")
+    assert min(a, b) >= 0.90 and min(loose) >= 0.95 and abs(len(d16) - len(ref)) <= 1
+    io_b, _ = run_policy(om.spp_forward, sd, x, C.SPP_ANCHORS, 80, policy="bf16")
+    db, _ = onms.non_max_suppression(io_b.numpy().copy(), sep["conf_thres"], sep["nms_thres"])
+    am, bm = strict_share(db[0], d16), strict_share(d16, db[0])
+    print(f"[separable] against the CPU rounding model ({len(db[0])} detections): {am:.3f} / {bm:.3f}")
+    assert min(am, bm) >= 0.90 and min(strict_share(db[0], d16, 0.7, 0.06), strict_share(d16, db[0], 0.7, 0.06)) >= 0.95
+    model.precision = "fp32"
+    with torch.no_grad():
+        io32, _ = model(x.to(DEV))
+        dets32, idx32 = non_max_suppression(io32, sep["conf_thres"], sep["nms_thres"], with_indices=True)
+    d32, k32 = dets32[0].cpu().numpy(), idx32[0].cpu().numpy()
+    assert np.array_equal(k32, g["nms_kept_0"]), "fp32 mode: kept-index set differs from the reference's"
+    assert np.array_equal(d32[:, 6], ref[:, 6])
+    np.testing.assert_allclose(d32[:, 4:6], ref[:, 4:6], rtol=0, atol=2e-4)
+    dbox = np.abs(d32[:, :4] - ref[:, :4]).max(1)
+    print(f"[separable] fp32 mode: {len(d32)} detections, kept-index set equal, boxes within {dbox.max():.4f} px of the reference's")
+    assert dbox.max() <= 0.05
+
+
 def test_bf16_path_within_its_rounding_budget():
     """SPP-640 at full size: the distance of the HIP bf16 forward to the fp32 reference must be the distance that bf16
     operand rounding alone produces — the oracle re-run under the fast path's rounding policy (oracle/policy.py: BN folded
@@ -1385,7 +1439,7 @@ def test_bf16_path_within_its_rounding_budget():
     assert got <= 1.25 * budget + 1e-4
     # the stated end-to-end bound of the bf16 mode on this configuration: raw head logits within 1.0 of the reference
     # (measured 0.71; logit std is 25..40 here), hence scores within 0.25 (the sigmoid's slope is <= 1/4)
-    _assert_model_close(io.cpu(), io_ref, "spp_640 HIP bf16 vs fp32 reference", score_max=0.25, score_rms=1e-2, box_rel_tol=0.02)
+    _assert_model_close(io.cpu(), io_ref, "spp_640 HIP bf16 vs fp32 reference", score_max=0.18, score_rms=1e-2, box_rel_tol=0.02)
 
 
 def _seeded_batch(n, hw, first_seed=0):
@@ -1411,14 +1465,14 @@ def test_headline_config_bs32_two_streams():
         assert type(model.plan_for(xd)).__name__ == "StreamedPlan"
         io, p = model(xd)
         io_c = io.cpu()
-        _assert_model_close(io_c[:1][:, g["rows"]], torch.from_numpy(g["io_rows"]), "spp_640x32 image 0 / golden rows", score_max=0.25, score_rms=1e-2)
+        _assert_model_close(io_c[:1][:, g["rows"]], torch.from_numpy(g["io_rows"]), "spp_640x32 image 0 / golden rows", score_max=0.18, score_rms=1e-2)
         model.n_streams = 1
         for half in (0, 1):
             io_h, _ = model(xd[16 * half:16 * half + 16])
             assert torch.equal(io_h, io[16 * half:16 * half + 16]), "two-stream run differs from the one-stream run of its half"
         for i in (0, 13, 31):
             io_ref, _ = om.spp_forward(sd, x[i:i + 1], C.SPP_ANCHORS, 80)
-            _assert_model_close(io_c[i:i + 1], io_ref, f"spp_640x32 image {i} vs fp32 oracle", score_max=0.25, score_rms=1e-2)
+            _assert_model_close(io_c[i:i + 1], io_ref, f"spp_640x32 image {i} vs fp32 oracle", score_max=0.225, score_rms=1e-2)       # measured over images 0 / 13 / 31: 0.140 / 0.178 / 0.180 (+ 25 %)
         model.n_streams = 2
         dets = model.detect(xd, **C.NMS_FULL)
     odets, _ = onms.non_max_suppression(io_c.numpy().copy(), **C.NMS_FULL)
@@ -2095,5 +2149,8 @@ def test_bench_line_contract(extra):
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["config"]["pipelines"].startswith("2 x " + ("sub-batches" if extra else "whole batches"))
     assert d["config"]["mean_detections_per_image"] > 0
+    assert rf["ms_per_step_layers" if rf["bound"] == "hbm" else "ms_per_step_conv"] <= d["ms_per_step"] * 1.02      # a measured span, not an assumption
+    assert d["config"]["sustained_images_per_s"] > 0
     if not extra:
         assert d["config"]["detect_api_images_per_s"] > 0 and d["config"]["detect_stream_api_images_per_s"] > 0
+        assert 0 < d["config"]["fp32_mode_images_per_s"] < d["value"]

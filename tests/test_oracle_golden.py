@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import _cases as C
-from helpers import build_case, load_golden, oracle_forward
+from helpers import build_case, build_separable_case, load_golden, oracle_forward, strict_share
 from oracle import blocks as ob
 from oracle import nms as onms
 
@@ -77,6 +77,42 @@ def test_model_full_size_samples(name):
         assert list(t.shape) == g[f"p{k}_shape"].tolist()
     dets, kept = onms.non_max_suppression(io.numpy().copy(), **C.NMS_FULL)
     _check_nms(dets, kept, g, prefix="nms_")
+
+
+def test_separable_full_size_case():
+    """tests/_cases.py::SEPARABLE (round 3): the oracle reproduces the reference on the conditioned full-size case - sampled rows
+    and column sums of io bit / 1e-9 equal, the 22 detections with identical kept indices - the calibration that the golden stores
+    is what `calibrate_separable_heads` derives from the oracle's own raw heads (so the stored arrays are data, not a free choice),
+    and the oracle's bf16-policy re-run pairs with it strictly in both directions (the property the seed was selected for)."""
+    from oracle import models as om
+    from oracle.policy import run_policy
+    from pytorch_yolo_amd.utils.synthetic import synth_state_dict
+    sep = C.SEPARABLE
+    model, sd, x, g = build_separable_case()
+    with torch.no_grad():
+        io, p = om.spp_forward(sd, x, C.SPP_ANCHORS, 80)
+    assert list(io.shape) == g["io_shape"].tolist()
+    assert np.array_equal(io.numpy()[:, g["rows"]], g["io_rows"])
+    np.testing.assert_allclose(io.numpy().astype(np.float64).sum(1), g["io_colsum"], rtol=1e-9)
+    dets, kept = onms.non_max_suppression(io.numpy().copy(), sep["conf_thres"], sep["nms_thres"])
+    _check_nms(dets, kept, g, prefix="nms_")
+    assert int(g["nms_count_0"]) == 22 and float(g["nms_dets_0"][:, 4].min()) > 0.8 and int(g["n_between_04_06"]) == 0
+    conf = g["nms_dets_0"][:, 4]
+    assert len(np.unique(conf)) == len(conf)                                   # no ties: the reference's argsort order is defined
+    # the stored head BN = the calibration rule applied to the un-calibrated model's raw heads
+    sd0 = synth_state_dict(model.state_dict(), sep["weight_seed"], n_class=80)
+    with torch.no_grad():
+        _, p0 = om.spp_forward(sd0, x, C.SPP_ANCHORS, 80)
+    wk = [h + ".sequence.batch_norm.weight" for h in C.SEPARABLE_HEADS]
+    bk = [h + ".sequence.batch_norm.bias" for h in C.SEPARABLE_HEADS]
+    new_w, new_b = C.calibrate_separable_heads([sd0[k].numpy() for k in wk], [sd0[k].numpy() for k in bk], [t[0].numpy() for t in p0], 80,
+                                               sep["per_anchor"], sep["span"], sep["gamma_obj"], sep["cls_gain"])
+    for k in range(3):
+        assert np.array_equal(new_w[k], g[f"head_bn_weight_{k}"]) and np.array_equal(new_b[k], g[f"head_bn_bias_{k}"])
+    # the rounding model (fp32 oracle re-run under the product's bf16 rounding points) carries these detections strictly
+    io_b, _ = run_policy(om.spp_forward, sd, x, C.SPP_ANCHORS, 80, policy="bf16")
+    db, _ = onms.non_max_suppression(io_b.numpy().copy(), sep["conf_thres"], sep["nms_thres"])
+    assert strict_share(g["nms_dets_0"], db[0]) == 1.0 and strict_share(db[0], g["nms_dets_0"]) == 1.0
 
 
 def _check_nms(dets, kept, g, prefix=""):

@@ -3,7 +3,7 @@
 rounds=$1; shift
 for r in $(seq 1 $rounds); do
   for pp in "$@"; do
-    YOLO_CONV_PP=$pp python bench.py --steps 30 --warmup 5 --no-api --no-cpu-baseline 2>/dev/null > /tmp/ab_line.json
+    YOLO_CONV_PP=$pp python bench.py --steps 30 --warmup 5 --no-api --no-cpu-baseline --no-sustained 2>/dev/null > /tmp/ab_line.json
     python - "$pp" <<'PY'
 import json, sys
 d = json.load(open('/tmp/ab_line.json'))

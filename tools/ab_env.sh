@@ -6,7 +6,7 @@ while [ $# -gt 0 ] && [ "$1" != "--" ]; do vals+=("$1"); shift; done
 [ "$1" == "--" ] && shift
 for r in $(seq 1 $rounds); do
   for v in "${vals[@]}"; do
-    env "$var=$v" python bench.py --steps 30 --warmup 5 --no-api --no-cpu-baseline "$@" 2>/tmp/ab_err.txt > /tmp/ab_line.json || { tail -5 /tmp/ab_err.txt; continue; }
+    env "$var=$v" python bench.py --steps 30 --warmup 5 --no-api --no-cpu-baseline --no-sustained "$@" 2>/tmp/ab_err.txt > /tmp/ab_line.json || { tail -5 /tmp/ab_err.txt; continue; }
     python - "$var" "$v" <<'PY'
 import json, sys
 d = json.load(open('/tmp/ab_line.json'))
