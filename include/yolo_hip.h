@@ -176,6 +176,10 @@ YOLO_API int yolo_spp_fwd(void* buf, int n, int h, int w, int c, yolo_stream_t s
  *  ([cout_pad1][kpad1]).  y must not alias x.  yolo_resunit_supported(): C in {64,128,256} on maps >= 80x80 that
  *  tile well by 16x16; other shapes use two yolo_conv2d_fwd calls. */
 YOLO_API int yolo_resunit_supported(int c, int h, int w);
+/** Which kernel yolo_resunit_fwd launches for a C-channel unit on n maps of h x w: 0 not supported, 1 the generic 16x16-tile kernel
+ *  (slower than the two-launch path above C = 64: a planner should not fuse there), 2 the persistent 64-channel kernel, 3 the
+ *  20-pixel-wide tile kernels (conv_resunit_t20.hip).  No launch, works without a GPU. */
+YOLO_API int yolo_resunit_form(int c, int n, int h, int w);
 YOLO_API int yolo_resunit_fwd(const void* x, const void* w1_packed, const float* b1, const void* w2_packed,
                               const float* b2, void* y, void* y_preadd, const YoloConvDesc* d, int kpad1,
                               int cout_pad1, yolo_stream_t s);

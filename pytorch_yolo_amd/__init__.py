@@ -15,7 +15,15 @@ import os as _os
 # sub-batch pipelines on one queue run one after the other (measured: 5,740 -> 4,100 images/s in the sharded bench, -3 % in the
 # one-GPU one).  Read by the HIP runtime when it initialises, i.e. at the first torch.cuda call: import this package before that,
 # or export the variable yourself.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if "GPU_MAX_HW_QUEUES" not in _os.environ:
+    _os.environ["GPU_MAX_HW_QUEUES"] = "8"
+    import sys as _sys
+    _torch = _sys.modules.get("torch")
+    if _torch is not None and _torch.cuda.is_initialized():      # too late: the runtime has read its default of 4
+        import warnings as _warnings
+        _warnings.warn("pytorch_yolo_amd was imported after torch.cuda was initialised and GPU_MAX_HW_QUEUES is not set: HIP keeps 4 "
+                       "hardware queues and the detect() pipelines will share them (-3 % on one GPU, -29 % when sharded). Export "
+                       "GPU_MAX_HW_QUEUES=8 or import pytorch_yolo_amd before the first torch.cuda call.", RuntimeWarning, stacklevel=2)
 
 from .models import (LiteYOLOv3, YOLOv3, YOLOv3SPP, YOLOv3Tiny, YOLOv3TinyEfficient, YOLOv3TinyMobile, YOLOv3TinyShuffle,
                      YOLOv3TinySqueeze)

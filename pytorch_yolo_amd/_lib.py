@@ -66,6 +66,7 @@ SIGNATURES = {
     "yolo_stem_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.POINTER(YoloConvDesc), C.c_void_p]),
     "yolo_resunit_supported": (C.c_int, [C.c_int] * 3),
+    "yolo_resunit_form": (C.c_int, [C.c_int] * 4),
     "yolo_resunit_fwd": (C.c_int, [C.c_void_p] * 7 + [C.POINTER(YoloConvDesc), C.c_int, C.c_int, C.c_void_p]),
     "yolo_conv3x3_pool_supported": (C.c_int, [C.c_int] * 2),
     "yolo_conv3x3_pool_fwd": (C.c_int, [C.c_void_p] * 4 + [C.POINTER(YoloConvDesc), C.c_int, C.c_void_p]),

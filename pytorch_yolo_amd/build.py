@@ -26,7 +26,6 @@ SOURCES = {
     "conv_mbconv.hip": [],
     "conv_small.hip": [],
     "conv_f32.hip": ["-ffp-contract=off"],
-    "conv_pp.hip": [],
     "conv1x1_stream.hip": [],
     "pointwise.hip": [],
     "efficient.hip": [],

@@ -122,128 +122,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const ConvArgs a
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Second form (NOT shipped: YOLO_CONV_PP bit 4096 selects it for A/B; 0.0198 vs 0.0149 ms at 512 -> 256 @40x40 x16, 0.0302 vs
-// 0.0226 at 1024 -> 512 @20x20 x32 - the tiled kernel's 16 waves hide the pixel fetch better than one double-buffered tile
-// per 8 waves), for the long-K 1x1 layers of the 40x40 / 20x20 maps (512 -> 256, 1024 -> 512): 8 waves, a workgroup owns NB
-// couts (a wave NB / 8 = 16 or 32 of them, its weights for the WHOLE K in registers: K / 32 fragments of 4 registers each),
-// one persistent workgroup per CU walks P-pixel tiles of its cout block with TWO pixel buffers: the LDS-DMA of tile t + 1
-// flies while tile t is multiplied.  The tiled kernel needs 1.56 rounds of 128x256 tiles for these layers and pays a prologue,
-// 8-16 barriers and an epilogue per round; here a tile costs one wait and three barriers.
-template <int NB, int K, int P>   // couts per workgroup (128 or 256), input channels (512 or 1024), pixels per tile (64 or 32)
-__global__ __launch_bounds__(512) void conv1x1_stream8_kernel(const ConvArgs a, int n_px_tiles, int n_cout_blocks) {
-  constexpr int NF = NB / 128, KC = K / 32, PB = P / 16;      // cout fragments per wave, 32-channel chunks, 16-pixel blocks per tile
-  constexpr int XB = KC * P * 64;                              // bytes of a pixel tile
-  constexpr int SP = NB * 2 + 16;                              // staging pitch
-  constexpr int NPIECE = KC * PB, PPW = NPIECE / 8;            // LDS-DMA pieces per tile, per wave
-  constexpr int LPR = NB / 8, RPI = 64 / LPR;                  // lanes per output pixel row, rows per wave-instruction
-  constexpr int NST = P / (8 * RPI);                           // output store instructions per wave and tile
-  static_assert(NPIECE % 8 == 0 && P * SP <= XB && 2 * XB <= 160 * 1024 && P % (8 * RPI) == 0 && PPW + NST < 64, "shape");
-  __shared__ __attribute__((aligned(16))) char smem[2 * XB];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const YoloConvDesc& d = a.d;
-  const ActParams ap(d.act);
-  const int c16 = lane & 15, q = lane >> 4;
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
-  const uint32_t y_pitch = (uint32_t)d.out_c_total * 2u;
-  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (uint32_t)a.M * y_pitch, 0x00020000);
-
-  // work: cout block cb = blockIdx % n_cout_blocks (fixed: the weights stay), pixel tiles first, first + stride, ...
-  const int cb = blockIdx.x % n_cout_blocks, first = blockIdx.x / n_cout_blocks, stride = gridDim.x / n_cout_blocks;
-  const int n0 = cb * NB;
-  bf16x8 wreg[NF][KC];
-  f32x4 bv[NF];
-#pragma unroll
-  for (int f = 0; f < NF; ++f) {
-    const int row = n0 + wave * 16 * NF + f * 16 + c16;
-#pragma unroll
-    for (int kc = 0; kc < KC; ++kc) wreg[f][kc] = *reinterpret_cast<const bf16x8*>(a.w + (long)row * d.kpad + kc * 32 + q * 8);
-    bv[f] = *reinterpret_cast<const f32x4*>(a.bias + n0 + wave * 16 * NF + f * 16 + q * 4);
-  }
-  const int drow = lane >> 2, dchunk = (lane & 3) ^ swz32(lane >> 4);
-  const uint32_t x_pitch = (uint32_t)d.in_c_total * 2u;
-  const uint32_t lane_src = (uint32_t)drow * x_pitch + (uint32_t)(d.in_c_offset + dchunk * 8) * 2u;
-  const uint32_t xfrag = (uint32_t)(c16 * 64 + ((q ^ swz32(c16 >> 2)) << 4));
-  const int orow = lane / LPR, ocol = lane % LPR;
-
-  auto issue = [&](int t, int buf) {                           // pixel tile t -> buffer buf: piece = (chunk kc, pixel block pb)
-    const int p0 = t * P;
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const int piece = i * 8 + wave, kc = piece / PB, pb = piece % PB;
-      const int px = p0 + pb * 16 + drow;
-      const uint32_t vo = (t < n_px_tiles && px < a.M) ? (uint32_t)(p0 + pb * 16) * x_pitch + lane_src : kOobOffset;
-      lds_dma16s(rx, smem + buf * XB + piece * 1024, vo, (uint32_t)kc * 64u);
-    }
-  };
-
-  if (first < n_px_tiles) issue(first, 0);
-  int buf = 0;
-  for (int t = first; t < n_px_tiles; t += stride, buf ^= 1) {
-    issue(t + stride, buf ^ 1);                       // (beyond the last tile: zero fill, keeps the vmcnt arithmetic uniform)
-    // tile t has landed; what may stay in flight: tile t + stride's pieces and - issued between the two - the previous tile's
-    // stores (waiting for their acknowledgements would put 1-2 us of store latency on every tile)
-    if (t == first) wait_vmcnt<PPW>();
-    else wait_vmcnt<PPW + NST>();
-    __builtin_amdgcn_s_barrier();
-    const char* const xb = smem + buf * XB;
-    f32x4 acc[NF][PB];
-#pragma unroll
-    for (int f = 0; f < NF; ++f)
-#pragma unroll
-      for (int j = 0; j < PB; ++j) acc[f][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kc = 0; kc < KC; ++kc)
-#pragma unroll
-      for (int j = 0; j < PB; ++j) {
-        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xb + (kc * PB + j) * 1024 + xfrag);
-#pragma unroll
-        for (int f = 0; f < NF; ++f) acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[f][kc], xf, acc[f][j], 0, 0, 0);
-      }
-    wait_lds();
-    __builtin_amdgcn_s_barrier();                     // every wave is done reading the tile: stage the result over it
-    char* const sb = smem + buf * XB;
-    auto stage = [&](auto act) {
-#pragma unroll
-      for (int f = 0; f < NF; ++f)
-#pragma unroll
-        for (int j = 0; j < PB; ++j) {
-          bf16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (bf16_t)act(acc[f][j][e] + bv[f][e]);
-          *reinterpret_cast<bf16x4*>(sb + (j * 16 + c16) * SP + (wave * 16 * NF + f * 16 + q * 4) * 2) = o;
-        }
-    };
-    if (ap.swish) stage([](float v) { return v / (1.f + expf(-v)); });
-    else stage([&](float v) { return ap.plain(v); });
-    wait_lds();
-    __builtin_amdgcn_s_barrier();
-    const int p0 = t * P;
-#pragma unroll
-    for (int i = 0; i < NST; ++i) {
-      const int row = (i * 8 + wave) * RPI + orow;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(sb + row * SP + ocol * 16);
-      const uint32_t vo = p0 + row < a.M ? (uint32_t)(p0 + row) * y_pitch + (uint32_t)(d.out_c_offset + n0 + ocol * 8) * 2u : kOobOffset;
-      __builtin_amdgcn_raw_buffer_store_b128(v, ry, vo, 0, 0);
-    }
-    wait_lds();                                       // the rows are in registers: the buffer may take tile t + 2 stride after the
-    __builtin_amdgcn_s_barrier();                     // next iteration's first barrier... it is issued at that iteration's top
-  }
-  wait_vmcnt<0>();                                    // the zero-fill DMAs of the tail have landed before the LDS is released
-}
-
-template <int NB, int K, int P>
-int launch_stream8(const ConvArgs& a, hipStream_t s) {
-  const int px_tiles = (a.M + P - 1) / P, cbs = a.d.cout / NB;
-  int grid = 256 / cbs * cbs;                         // one persistent workgroup per CU, a multiple of the cout blocks
-  if (grid > px_tiles * cbs) grid = px_tiles * cbs;
-  if (pick_only("stream1x1_8waves<%d couts,K %d,%d px> grid %d", NB, K, P, grid)) return 0;
-  hipLaunchKernelGGL((conv1x1_stream8_kernel<NB, K, P>), dim3((unsigned)grid), dim3(512), 0, s, a, px_tiles, cbs);
-  return yolo_check_launch("yolo_conv2d_fwd(1x1 stream8)");
-}
-
 template <int N, int K>
 int launch_stream(const ConvArgs& a, hipStream_t s) {
   const int tiles = (a.M + 127) / 128;
@@ -261,12 +139,6 @@ int yolo_conv::launch_stream1x1(const ConvArgs& a, int force, hipStream_t s) {
   if (d.ksize != 1 || d.stride != 1 || d.pad != 0 || d.upsample2x || d.out_dtype != YOLO_DT_BF16 || a.res || a.aux) return 1;
   if (d.in_c_offset % 8 || d.in_c_total % 8 || d.out_c_offset % 8 || d.out_c_total % 8) return 1;
   if ((size_t)a.M * d.out_c_total * 2 >= kOobOffset) return 1;
-  // second form: the long-K layers of the small maps (force bit 2)
-  if (force & 2) {
-    if (d.cin == 512 && d.cout % 256 == 0) return a.M >= 40000 ? launch_stream8<256, 512, 64>(a, s) : launch_stream8<256, 512, 32>(a, s);
-    if (d.cin == 1024 && d.cout % 128 == 0) return launch_stream8<128, 1024, 32>(a, s);
-    if (force == 2) return 1;
-  }
   // Shipped rule: the short-K layers of the large maps (M >= 40000 pixels: the 160x160 and 80x80 maps at 16 images).  Per 16
   // images against the tiled kernel: 128 -> 64 @160x160 0.0446 -> 0.0268 ms, 256 -> 128 @80x80 0.0211 -> 0.0191 (32 images:
   // 0.0412 -> 0.0322).  With apply_act's former branch chain in the staging loop the same kernel LOST to the tiled one

@@ -48,7 +48,6 @@ struct ConvArgs {
   int splits;
   float* ws;
   int* cnt;
-  int blk_off, blk_total;   // a launch that covers work items [blk_off, blk_off + gridDim.x) of blk_total (0: the grid is the whole list)
   int debug;    // YOLO_CONV_DEBUG, tuning / ablation only (results are wrong with bits 1..8 set):
                 //   1 no pixel DMA   2 no weight DMA   4 no MFMA   8 no epilogue   16 no LDS-staged epilogue
                 //   32 no halo kernel   128 no 128x256 tiles   256 no loader waves   512 8-wave 256x256 tiles
@@ -303,6 +302,7 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nblk) {
 
 // yolo_conv2d_pick (the tile-rule regression guard): while pick_buffer() is non-null the launch functions write the name of the
 // kernel instance they would launch there and return 0 WITHOUT launching (no GPU needed).
+bool resunit_t20_applies(int c, int n, int h, int w);   // conv_resunit_t20.hip: the shipped rule of the 20-pixel-wide tile kernels
 int launch_resunit_t20(const ConvArgs& c, const bf16_t* w1, const float* b1, int kpad1, uint32_t w1_bytes, bool force, hipStream_t s);
 int launch_cus();                  // compute units the coming launches may use (256, or a CU-masked stream's share)
 char* pick_buffer();
@@ -311,7 +311,6 @@ bool pick_only(const char* fmt, ...);   // true (and the name recorded) in pick 
 int launch_halo3x3(const ConvArgs& a, hipStream_t s);   // conv3x3_halo.hip; returns 1 if it does not apply
 int launch_t20_3x3(const ConvArgs& a, int force, hipStream_t s);   // conv3x3_t20.hip (20x20 output tiles); 1 if it does not apply
 int launch_stream1x1(const ConvArgs& a, int force, hipStream_t s);   // conv1x1_stream.hip (weight-stationary 1x1 on large maps); 1 if it does not apply
-int launch_pingpong(const ConvArgs& a, int which, hipStream_t s);   // conv_pp.hip (1: 256x256, 2: 128x256 tiles); 1 if it does not apply
 int launch_conv1_nchw(const ConvArgs& a, const float* x_nchw, int cin_real, bool pool, hipStream_t s);
 int launch_conv1_s2_nchw(const ConvArgs& a, const float* x_nchw, int cin_real, hipStream_t s);   // conv_small.hip; 1 if it does not apply
 

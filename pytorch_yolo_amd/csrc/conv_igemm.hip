@@ -614,7 +614,8 @@ bool pick_only(const char* fmt, ...) {
 namespace {
 int conv_variant_override = -1;
 int conv_debug_flags = 0;   // tuning hook (YOLO_CONV_VARIANT), see yolo_conv2d_launch
-int conv_pp_mask = 0;       // YOLO_CONV_PP: which tile rules hand their layers to the ping-pong kernel (conv_pp.hip)
+int conv_pp_mask = 0;       // YOLO_CONV_PP / yolo_set_tuning(2, .): kernel-family selection for tests and A/B runs - 8 no halo kernel,
+                            // 16 the 20x20-tile kernels on every layer they can compute, 64 ... on none, 1024 no streaming 1x1, 2048 ... on every layer it can compute
 
 // split-K request of the current yolo_conv2d_splitk_fwd call (consumed by conv2d_launch_ex)
 struct SplitK {
@@ -728,7 +729,6 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
   a.x_bytes = (uint32_t)x_bytes;
   a.w_bytes = (uint32_t)w_bytes;
   a.debug = conv_debug_flags;
-  a.blk_off = a.blk_total = 0;
   a.splits = g_splitk.splits;
   a.ws = g_splitk.ws;
   a.cnt = g_splitk.cnt;
@@ -745,17 +745,16 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
   const bool epi = d.out_dtype == YOLO_DT_BF16 && d.cout % 32 == 0 && d.out_c_offset % 8 == 0 && d.out_c_total % 8 == 0 &&
                    (!res || (d.res_c_offset % 8 == 0 && d.res_c_total % 8 == 0)) &&
                    (!y_aux || (d.aux_c_offset % 8 == 0 && d.aux_c_total % 8 == 0)) && !(conv_debug_flags & 16);
-  // 3x3/s1 layers whose maps 20x20 tiles cover and fill the chip with (conv3x3_t20.hip).  YOLO_CONV_PP bit 16: every layer the
-  // kernel can compute, bit 32: ... with 256 couts per workgroup where cout allows, bit 64: never, bit 128: every such layer with
-  // the second form (4 waves, weights straight to registers, two workgroups per CU).
+  // 3x3 layers whose maps 20x20 tiles cover and fill the chip with (conv3x3_t20.hip: stride 1 and, round 3, stride 2).
+  // YOLO_CONV_PP bit 16: every layer the kernels can compute, bit 64: never.
   if (epi && std_out && conv_variant_override < 0 && !(conv_pp_mask & 64) && a.splits <= 1) {
-    const int rc = launch_t20_3x3(a, (conv_pp_mask & 16 ? 1 : 0) | (conv_pp_mask & 32 ? 3 : 0) | (conv_pp_mask & 128 ? 5 : 0), s);
+    const int rc = launch_t20_3x3(a, conv_pp_mask & 16 ? 1 : 0, s);
     if (rc != 1) return rc;
   }
   // short-K 1x1 layers on the large maps: weight-stationary streaming kernel (conv1x1_stream.hip).  YOLO_CONV_PP bit 1024: never,
-  // bit 2048: every layer it can compute, bit 4096: the 8-wave form for the long-K layers (512 -> 256, 1024 -> 512).
+  // bit 2048: every layer it can compute.
   if (epi && std_out && d.ksize == 1 && conv_variant_override < 0 && !(conv_pp_mask & 1024) && a.splits <= 1) {
-    const int rc = launch_stream1x1(a, (conv_pp_mask & 2048 ? 1 : 0) | (conv_pp_mask & 4096 ? 2 : 0), s);
+    const int rc = launch_stream1x1(a, conv_pp_mask & 2048 ? 1 : 0, s);
     if (rc != 1) return rc;
   }
   if (epi && std_out && !(conv_debug_flags & 32) && conv_variant_override < 0 && !(conv_pp_mask & 8)) {   // large 3x3/s1 maps: halo-staged kernel
@@ -804,16 +803,6 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
   // 16x16x32 MFMA mainloop (same LDS traffic and cycles per FLOP as 32x32x16; the chip holds a higher clock on
   // it: +2..3 % measured on every shape).  YOLO_CONV_DEBUG bit 2048 falls back to 32x32x16.
   if (epi && !(conv_debug_flags & 2048)) {
-    if (conv_pp_mask && a.splits <= 1) {      // ping-pong main loop (conv_pp.hip): bit 1 the 256x256 layers, bit 2 the 128x256 ones,
-      int which = 0;                           // bit 4: every layer either tile shape fits
-      if ((conv_pp_mask & 1) && pick == 5) which = 1;
-      if ((conv_pp_mask & 2) && pick == 12) which = 2;
-      if ((conv_pp_mask & 4) && d.cout % 256 == 0) which = ((M + 255) / 256) * (d.cout / 256) >= 160 ? 1 : 2;
-      if (which) {
-        const int rc = launch_pingpong(a, which, s);
-        if (rc != 1) return rc;
-      }
-    }
     switch (pick) {
       case 5:
         // 16 waves (64x64 each) instead of 8 (64x128): four waves per SIMD hide the LDS-DMA issue stalls of one another
@@ -883,7 +872,6 @@ static int conv1_nchw(const float* x_nchw, int cin_real, const void* w_packed, c
   a.x_bytes = 0;
   a.w_bytes = 0;
   a.debug = 0;
-  a.blk_off = a.blk_total = 0;
   a.splits = 1;
   a.ws = nullptr;
   a.cnt = nullptr;

@@ -578,6 +578,12 @@ extern "C" int yolo_resunit_supported(int c, int h, int w) {
   return (double)h * w >= 0.85 * 256.0 * tiles && (long)h * w >= 80 * 80;
 }
 
+extern "C" int yolo_resunit_form(int c, int n, int h, int w) {
+  if (!yolo_resunit_supported(c, h, w)) return 0;
+  if (resunit_t20_applies(c, n, h, w)) return 3;
+  return c == 64 ? 2 : 1;
+}
+
 extern "C" int yolo_resunit_fwd(const void* x, const void* w1_packed, const float* b1, const void* w2_packed, const float* b2,
                                 void* y, void* y_preadd, const YoloConvDesc* dp, int kpad1, int cout_pad1,
                                 yolo_stream_t s) {

@@ -674,8 +674,7 @@ template <int CMID, int TPH>
 int launch_ruw(const RU20Args& ra, bool force, hipStream_t s) {
   const YoloConvDesc& d = ra.c.d;
   const long tiles = (long)d.n * ((d.h + 4 * TPH - 1) / (4 * TPH)) * ((d.w + kT - 1) / kT);
-  // partial tiles idle lanes (and MFMAs); few tiles leave CUs without their two workgroups
-  if (!force && ((double)d.n * d.h * d.w < 0.9 * (80.0 * TPH) * tiles || tiles < 512)) return 1;
+  if (!force && !resunit_t20_applies(2 * CMID, d.n, d.h, d.w)) return 1;
   if (tiles > 0x7fffffffL) return 1;
   if (pick_only("resunit_t20w<C %d, %dpx x %d couts, 4 waves> grid %ld", 2 * CMID, 80 * TPH, 2 * CMID, tiles)) return 0;
   hipLaunchKernelGGL((resunit_t20w_kernel<CMID, TPH>), dim3((unsigned)tiles), dim3(256), (ra.c.debug & 512) ? 40 * 1024 : 0, s, ra);   // bit 512: one workgroup per CU (diagnosis)
@@ -685,6 +684,16 @@ int launch_ruw(const RU20Args& ra, bool force, hipStream_t s) {
 }  // namespace
 
 namespace yolo_conv {
+
+// The shipped rule: do the 20-pixel-wide tile kernels take a C-channel unit on n maps of h x w?  Partial tiles idle lanes (and
+// MFMAs): tiles must cover >= 90 % of the map; few tiles leave CUs without their two workgroups: >= 256 tiles of 20x20 for C = 64,
+// >= 512 of 20x20 (C = 128) or 20x8 (C = 256).
+bool resunit_t20_applies(int c, int n, int h, int w) {
+  const int th = c == 256 ? 8 : 20;
+  if (c != 64 && c != 128 && c != 256) return false;
+  const long tiles = (long)n * ((h + th - 1) / th) * ((w + kT - 1) / kT);
+  return (double)n * h * w >= 0.9 * (20.0 * th) * tiles && tiles >= (c == 64 ? 256 : 512);
+}
 
 // 1: not this kernel's case (the caller falls back to the 16x16-tile kernels)
 int launch_resunit_t20(const ConvArgs& c, const bf16_t* w1, const float* b1, int kpad1, uint32_t w1_bytes, bool force, hipStream_t s) {
@@ -706,8 +715,8 @@ int launch_resunit_t20(const ConvArgs& c, const bf16_t* w1, const float* b1, int
   if (d.cout == 128) return launch_ruw<64, 5>(ra, force, s);
   if (d.cout == 256) return launch_ruw<128, 2>(ra, force, s);
   const long tiles = (long)d.n * ((d.h + kT - 1) / kT) * ((d.w + kT - 1) / kT);
-  // partial tiles idle lanes; few tiles: the persistent 16x16-tile kernel (YOLO_RESUNIT_DEBUG bit 64 forces this one)
-  if (!force && ((double)d.n * d.h * d.w < 0.9 * 400.0 * tiles || tiles < 256)) return 1;
+  // otherwise the persistent 16x16-tile kernel (YOLO_RESUNIT_DEBUG bit 64 forces this one)
+  if (!force && !resunit_t20_applies(64, d.n, d.h, d.w)) return 1;
   if (tiles > 0x7fffffffL) return 1;
   if (pick_only("resunit64_t20<400px x 64 couts, 4 waves> grid %ld", tiles)) return 0;
   hipLaunchKernelGGL(resunit64_t20_kernel, dim3((unsigned)tiles), dim3(256), 0, s, ra);

@@ -345,7 +345,6 @@ extern "C" int yolo_conv3x3_pool_fwd(const void* x, const void* w_packed, const 
   a.x_bytes = 0;
   a.w_bytes = 0;
   a.debug = 0;
-  a.blk_off = a.blk_total = 0;
   YOLO_SET_STAMPS(a);
   hipStream_t st = (hipStream_t)s;
   if (d.cin == 16) return d.cout == 32 ? launch_small<16, 32>(a, pool != 0, st) : launch_small<16, 64>(a, pool != 0, st);

@@ -290,7 +290,8 @@ class Plan:
                     or pa.attrs["act"] != nd.attrs["act"] or "up_into" in pa.attrs or mid.buf is not None
                     or nd.outs[0].f32):
                 continue
-            if (fuse_mask & c) and K.resunit_supported(c, res.h, res.w):
+            # (above 64 channels only where the 20-pixel-wide tile kernel takes the unit: the generic fused kernel is slower than two launches)
+            if (fuse_mask & c) and K.resunit_supported(c, res.h, res.w) and (c == 64 or K.resunit_form(c, res.n, res.h, res.w) == 3):
                 nd.attrs["fuse_pre"] = pa
                 pa.attrs["fused_away"] = True
         # 2c. MobileNetV2 inverted-residual blocks (1x1 expand + ReLU6, depthwise 3x3 + ReLU6, linear 1x1 [+ x]) with

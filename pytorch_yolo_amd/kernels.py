@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU6, DT_BF16, DT_F32, YoloConvDesc, YoloMbconvDesc,
                    check, load)
 
-__all__ = ["stream_ptr", "pack_input", "conv2d", "conv2d_pick", "stem", "resunit", "resunit_supported", "maxpool", "spp", "dwconv3x3", "dwconv", "se", "se_workspace_bytes", "mbconv", "mbconv_supported", "pack_mbconv", "conv3x3_pool", "conv3x3_pool_supported", "conv2d_splitk", "conv2d_splitk_plan", "decode", "head_decode", "head_decode_supported",
+__all__ = ["stream_ptr", "pack_input", "conv2d", "conv2d_pick", "stem", "resunit", "resunit_supported", "resunit_form", "maxpool", "spp", "dwconv3x3", "dwconv", "se", "se_workspace_bytes", "mbconv", "mbconv_supported", "pack_mbconv", "conv3x3_pool", "conv3x3_pool_supported", "conv2d_splitk", "conv2d_splitk_plan", "decode", "head_decode", "head_decode_supported",
            "nms_merge", "pack_conv_weight", "roundup", "run_ops"]
 
 
@@ -164,6 +164,11 @@ def stem(x_nchw, cin_real, w1_packed, b1, kpad1, w2_packed, b2, y, desc: YoloCon
 
 def resunit_supported(c: int, h: int, w: int) -> bool:
     return bool(load().yolo_resunit_supported(c, h, w))
+
+
+def resunit_form(c: int, n: int, h: int, w: int) -> int:
+    """0 not supported, 1 generic 16x16-tile kernel, 2 persistent 64-channel kernel, 3 the 20-pixel-wide tile kernels (yolo_resunit_form)."""
+    return int(load().yolo_resunit_form(c, n, h, w))
 
 
 def resunit(x, w1_packed, b1, w2_packed, b2, y, desc: YoloConvDesc, kpad1: int, cout_pad1: int, y_preadd=None):

@@ -1611,84 +1611,13 @@ def test_model_on_a_non_current_device():
     assert all(d is None or d.device.index == 1 for d in dets)
 
 
-PP_CASES = [
-    # n, h, w, cin, cout, k, stride, residual, aux, upsample, tiles (1: 256x256, 2: 128x256 via the tile rule the shape selects)
-    (16, 40, 40, 128, 512, 3, 1, True, True, False),      # 256x256 ping-pong tiles, residual + pre-add copy
-    (3, 37, 41, 64, 256, 3, 1, True, False, False),       # partial last pixel tile, image borders inside tiles
-    (4, 20, 20, 256, 512, 3, 1, False, False, False),     # 128x256 tiles (one round of the chip)
-    (2, 26, 26, 96, 256, 3, 2, False, False, False),      # stride 2, cin = 3 K tiles per tap
-    (5, 20, 20, 512, 256, 1, 1, False, False, True),      # 1x1 with the 2x nearest-upsample store
-    (2, 40, 40, 32, 256, 1, 1, True, False, False),       # a single K tile (prologue longer than the loop)
-]
-
-
-@pytest.mark.parametrize("case", PP_CASES, ids=lambda c: "n%d_%dx%d_c%d-%d_k%d_s%d_r%d_a%d_u%d" % tuple(int(v) for v in c))
-def test_pingpong_conv_kernel(case):
-    """conv_pp.hip (two wave groups half a phase apart, four-stage LDS-DMA ring) selected for every layer it takes
-    (yolo_set_tuning(2, 12)): against fp32 torch on the same bf16-rounded operands, and bit-equal to the shipped kernels'
-    result where both accumulate in the same K order."""
-    from pytorch_yolo_amd import kernels as K
-    from pytorch_yolo_amd._lib import ACT_LEAKY01, load
-    n, h, w, cin, cout, k, stride, use_res, use_aux, up = case
-    g = torch.Generator().manual_seed(hash(case) & 0xffff)
-    x = torch.randn(n, cin, h, w, generator=g)
-    wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
-    bias = torch.randn(cout, generator=g) * 0.1
-    pad = (k - 1) // 2
-    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
-    res = torch.randn(n, cout, ho, wo, generator=g) if use_res else None
-    in_ct, in_co = cin + 16, 8
-    xin = torch.zeros(n, h, w, in_ct, dtype=torch.bfloat16, device=DEV)
-    xin[..., in_co:in_co + cin] = _nhwc(x)
-    oh, ow = (2 * ho, 2 * wo) if up else (ho, wo)
-    out_ct, out_co = cout + 8, 8
-    rin = _nhwc(res) if use_res else None
-    wp, bp, kpad, cout_pad = K.pack_conv_weight(wt, bias, cin)
-    d = K.conv_desc(n=n, h=h, w=w, cin=cin, in_c_total=in_ct, in_c_offset=in_co, cout=cout, out_c_total=out_ct,
-                    out_c_offset=out_co, ksize=k, stride=stride, act=ACT_LEAKY01, kpad=kpad, cout_pad=cout_pad,
-                    upsample2x=int(up), res=(cout, 0) if use_res else (0, 0), aux=(cout + 8, 8) if use_aux else (0, 0))
-    outs = {}
-    lib = load()
-    old = lib.yolo_set_tuning(2, 0)
-    try:
-        for arm in (0, 12):
-            lib.yolo_set_tuning(2, arm)
-            y = torch.full((n, oh, ow, out_ct), -77.0, dtype=torch.bfloat16, device=DEV)
-            aux = torch.full((n, ho, wo, cout + 8), -77.0, dtype=torch.bfloat16, device=DEV) if use_aux else None
-            K.conv2d(xin, wp.to(DEV), bp.to(DEV), y, d, residual=rin, y_preadd=aux)
-            torch.cuda.synchronize()
-            outs[arm] = (y, aux)
-    finally:
-        lib.yolo_set_tuning(2, old)
-    ref = F.leaky_relu(F.conv2d(_bf16r(x), _bf16r(wt), bias, stride=stride, padding=pad), 0.1)
-    pre = ref
-    if use_res:
-        ref = ref + _bf16r(res)
-    if up:
-        ref = F.interpolate(ref, scale_factor=2, mode="nearest")
-    y, aux = outs[12]
-    torch.testing.assert_close(_nchw(y[..., out_co:out_co + cout]), ref, rtol=1e-2, atol=1e-2)
-    assert torch.all(y[..., :out_co] == -77.0)
-    if use_aux:
-        torch.testing.assert_close(_nchw(aux[..., 8:]), pre, rtol=1e-2, atol=1e-2)
-        assert torch.all(aux[..., :8] == -77.0)
-    same = torch.equal(outs[0][0], y)
-    print(f"[pp {case}] bit-equal to the shipped kernel: {same}; max abs diff {float((outs[0][0].float() - y.float()).abs().max()):.4g}")
-
-
 T20_CASES = [
-    # n, h, w, cin, cout, use_res, use_aux, knob (YOLO_CONV_PP bits: 16 = every layer the 20x20-tile kernel takes, 32 = 256-cout workgroups,
-    # 128 = the second form)
-    (2, 40, 40, 64, 256, True, True, 16 | 32),     # 4-wave form (256 couts, asm MFMAs, accumulators in both register files)
-    (2, 40, 40, 64, 256, True, False, 16),         # 8-wave form (128 couts, four pixel groups + the shared 25th patch)
+    # n, h, w, cin, cout, use_res, use_aux: conv3x3_t20v2_kernel (4 waves x 32 couts, weights straight to registers, block-wide staging)
+    # forced onto every shape class it takes (yolo_set_tuning(2, 16))
+    (2, 40, 40, 64, 256, True, True, 16),
     (1, 80, 80, 32, 128, False, False, 16),        # one channel chunk: prologue only, no halo double-buffering
-    (3, 37, 41, 96, 256, True, True, 16 | 32),     # partial tiles on both edges, three chunks (odd count)
-    (3, 37, 41, 96, 384, True, True, 16),          # ... and the 8-wave form with three cout tiles
-    (1, 20, 20, 256, 512, False, True, 16 | 32),   # one tile per image, eight chunks
-    (2, 40, 40, 64, 256, True, True, 16 | 128),    # second form (4 waves x 32 couts, weights straight to registers, block-wide staging)
-    (1, 80, 80, 32, 128, False, False, 16 | 128),  # ... one channel chunk
-    (3, 37, 41, 96, 384, True, True, 16 | 128),    # ... partial tiles, three chunks, three cout tiles
-    (1, 20, 20, 256, 512, False, True, 16 | 128),  # ... eight chunks
+    (3, 37, 41, 96, 384, True, True, 16),          # partial tiles on both edges, three chunks (odd count), three cout tiles
+    (1, 20, 20, 256, 512, False, True, 16),        # one tile per image, eight chunks
 ]
 
 
@@ -1913,10 +1842,7 @@ def test_efficientnet_variant_vs_oracle(n, h, w):
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout,act", [(2, 80, 80, 256, 128, "leaky"), (1, 160, 160, 128, 64, "leaky"), (3, 37, 41, 128, 128, "none"),
-                                              (1, 20, 20, 256, 64, "relu6"), (2, 13, 13, 256, 128, "swish"),
-                                              # the 8-wave form (two pixel buffers, a workgroup per cout block): long-K layers
-                                              (32, 40, 40, 512, 256, "leaky"), (16, 20, 20, 1024, 512, "leaky"), (3, 13, 13, 512, 256, "none"),
-                                              (2, 20, 20, 1024, 128, "swish"), (1, 7, 9, 512, 512, "leaky")])
+                                              (1, 20, 20, 256, 64, "relu6"), (2, 13, 13, 256, 128, "swish")])
 def test_conv1x1_stream_kernel(n, h, w, cin, cout, act):
     """conv1x1_stream.hip (weights stationary in registers, persistent workgroups, whole-K pixel tiles by LDS-DMA) forced onto
     every layer it takes (YOLO_CONV_PP bit 2048): against fp32 torch on the same bf16-rounded operands, channel-offset views on
@@ -1939,7 +1865,7 @@ def test_conv1x1_stream_kernel(n, h, w, cin, cout, act):
     old = lib.yolo_set_tuning(2, 0)
     try:
         for arm in (1024, 2048):
-            lib.yolo_set_tuning(2, arm | (4096 if arm == 2048 and cin >= 512 else 0))
+            lib.yolo_set_tuning(2, arm)
             y = torch.full((n, h, w, cout + 8), -77.0, dtype=torch.bfloat16, device=DEV)
             K.conv2d(xin, wp.to(DEV), bp.to(DEV), y, d)
             torch.cuda.synchronize()

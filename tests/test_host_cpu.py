@@ -113,7 +113,9 @@ def _ops(plan):
 
 
 def test_planner_spp_fusions():
-    plan = _dry_plan(YOLOv3SPP(anchors=C.SPP_ANCHORS).eval(), 640)
+    # (8 images: the smallest batch at which the 128-channel units at 160x160 give the fused kernel its 512 tiles; the CPU
+    # allocation of the activations is why this is not the bench's 32)
+    plan = _dry_plan(YOLOv3SPP(anchors=C.SPP_ANCHORS).eval(), 640, bs=8)
     ops = _ops(plan)
     kinds = [o.kind for o in ops]
     # the stem (conv1 + the stride-2 conv) reads the NCHW f32 batch itself and is ONE launch (yolo_stem_fwd)
@@ -125,6 +127,10 @@ def test_planner_spp_fusions():
     units = [o for o in ops if o.kind == OP_RESUNIT]
     assert [(u.conv.cout, u.conv.cin, u.conv.h) for u in units] == [(64, 32, 320), (128, 64, 160), (128, 64, 160)]
     assert all(u.y != u.x and u.w_pre and u.bias_pre for u in units)
+    # a single image leaves those units as two launches each: only the generic fused kernel would take them, and it is slower
+    kinds1 = [o.kind for o in _ops(_dry_plan(YOLOv3SPP(anchors=C.SPP_ANCHORS).eval(), 640, bs=1))]
+    assert kinds1.count(OP_RESUNIT) == 1 and kinds1.count(OP_CONV) == 69 and K.resunit_form(128, 1, 160, 160) == 1
+    assert K.resunit_form(128, 8, 160, 160) == 3 and K.resunit_form(256, 32, 80, 80) == 3 and K.resunit_form(64, 1, 320, 320) == 3
     convs = [o for o in ops if o.kind == OP_CONV]
     assert sum(1 for o in convs if o.residual) == 20                                        # every other Add is an epilogue
     assert all(o.residual == o.y for o in convs if o.residual)                              # ... written in place
