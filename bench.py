@@ -177,7 +177,7 @@ def dry_run(args, world, rank):
     dets = torch.full((bs, cap, 7), float(rank), dtype=torch.float32)
     count = torch.full((bs,), rank + 1, dtype=torch.int32)
     for _ in range(args.warmup + args.steps):
-        all_dets, all_count = gather_detections(dets, count)
+        all_dets, all_count = gather_detections(dets, count, equal_shards=True)
     dist.barrier()
     ok = all_count.tolist() == [r + 1 for r in range(world) for _ in range(bs)] and all_dets.shape[0] == world * bs
     if rank == 0:
@@ -356,7 +356,7 @@ def main():
         from pytorch_yolo_amd.distributed import detect_sharded
         k_api = max(3, min(args.steps, 20))
         with torch.no_grad():
-            call = (lambda: detect_sharded(model, x, CONF_THRES, NMS_THRES)) if sharded else (lambda: model.detect(x, CONF_THRES, NMS_THRES))
+            call = (lambda: detect_sharded(model, x, CONF_THRES, NMS_THRES, equal_shards=True)) if sharded else (lambda: model.detect(x, CONF_THRES, NMS_THRES))
             call()
             sync_all()
             ta = time.perf_counter()

@@ -22,20 +22,27 @@ def shard_bounds(total: int, world: int, rank: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_detections(dets: torch.Tensor, count: torch.Tensor, group=None, gather_cap: int = 1024, equal_shards: bool = False):
+def gather_detections(dets: torch.Tensor, count: torch.Tensor, group=None, gather_cap: int = 1024, equal_shards: bool = False,
+                      sizes=None):
     """All-gather per-rank NMS outputs.
 
     dets [bs_local, cap, 7] float32, count [bs_local] int32 (device or CPU tensors, any backend).
-    Ranks may hold different bs_local (``shard_bounds`` spreads a remainder over the first ranks): the shard sizes are
-    exchanged first and every shard is zero-padded to the largest one for the fixed-size all-gather; pass
-    ``equal_shards=True`` to skip that exchange when every rank is known to hold the same bs_local.
+    Ranks may hold different bs_local (``shard_bounds`` spreads a remainder over the first ranks); every shard is zero-padded to the
+    largest one for the fixed-size all-gather.  The shard sizes come from ``sizes`` (a list of world ints, e.g. from
+    ``shard_bounds``: nothing extra on the wire), or ``equal_shards=True`` (every rank holds this rank's bs_local); only when
+    neither is given are they exchanged first - one more collective and a blocking device-to-host copy per call.
     Returns (all_dets [sum bs_local, gather_cap, 7], all_count [sum bs_local]) on every rank, images in global
     (rank-major) order."""
     world = dist.get_world_size(group)
     bs, cap, _ = dets.shape
     g = min(gather_cap, cap)
-    sizes = [bs] * world
-    if not equal_shards:
+    if sizes is not None:
+        sizes = [int(v) for v in sizes]
+        if len(sizes) != world or sizes[dist.get_rank(group)] != bs:
+            raise RuntimeError(f"gather_detections: sizes {sizes} do not describe {world} ranks with {bs} images on this one")
+    elif equal_shards:
+        sizes = [bs] * world
+    else:
         mine = torch.tensor([bs], dtype=torch.int64, device=count.device)
         every = torch.empty((world,), dtype=torch.int64, device=count.device)
         dist.all_gather_into_tensor(every, mine, group=group)
@@ -122,12 +129,19 @@ def split_gathered(all_dets, all_count) -> List[Optional[torch.Tensor]]:
     return [all_dets[i, :n].clone() if n else None for i, n in enumerate(counts)]
 
 
-def detect_sharded(model, x_local: torch.Tensor, conf_thres=0.5, nms_thres=0.5, group=None, gather_cap: int = 1024):
+def detect_sharded(model, x_local: torch.Tensor, conf_thres=0.5, nms_thres=0.5, group=None, gather_cap: int = 1024, total: int = None,
+                   equal_shards: bool = False):
     """``detect()`` over a batch sharded by rank: returns the reference-style list for ALL images
-    (global order) on every rank.  ``x_local`` is this rank's contiguous slice of the batch."""
+    (global order) on every rank.  ``x_local`` is this rank's contiguous slice of the batch.
+    ``total`` = the global batch size when the shards follow ``shard_bounds`` (then the shard sizes are known without an exchange),
+    or ``equal_shards=True`` when every rank holds as many images as this one; with neither, the sizes are exchanged per call."""
     io, _ = model(x_local)
     dets, _, count = nms_raw(io, conf_thres, nms_thres)
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         from .utils.utils import split_detections
         return split_detections(dets, _, count)
-    return split_gathered(*gather_detections(dets, count, group, gather_cap))
+    sizes = None
+    if total is not None:
+        world = dist.get_world_size(group)
+        sizes = [hi - lo for lo, hi in (shard_bounds(total, world, r) for r in range(world))]
+    return split_gathered(*gather_detections(dets, count, group, gather_cap, equal_shards=equal_shards, sizes=sizes))

@@ -44,6 +44,18 @@ def _worker(rank, world, port, ret):
     a2, k2 = gather_detections(d2, c2, gather_cap=8)
     assert a2.shape == (7, 8, 7) and k2.tolist() == [i % 3 for i in range(7)]
     assert torch.all(a2[:4] == 1.0) and torch.all(a2[4:] == 2.0)
+    # the same with the shard sizes handed in (shard_bounds: no size exchange on the wire), and with equal shards declared
+    sizes = [b - a for a, b in (shard_bounds(7, world, r) for r in range(world))]
+    a3, k3 = gather_detections(d2, c2, gather_cap=8, sizes=sizes)
+    assert torch.equal(a3, a2) and torch.equal(k3, k2)
+    a4, k4 = gather_detections(dets, count, gather_cap=8, equal_shards=True)
+    assert torch.equal(a4, all_dets) and torch.equal(k4, all_count)
+    try:
+        gather_detections(d2, c2, gather_cap=8, sizes=[1, 1])      # sizes that contradict this rank's shard are an error
+        ok = False
+    except RuntimeError:
+        ok = True
+    assert ok
     dist.barrier()
     dist.destroy_process_group()
 
