@@ -379,10 +379,6 @@ def main():
                 stream_ips = round(n_out / (time.perf_counter() - ta), 2)
             assert n_out == bs * 2 * k_api
 
-    # YOLO_BENCH_STAGGER_MS (experiment knob, default off): inside the timed region the second pipeline's first batch starts that
-    # much later than the first one's, once, so that one pipeline's HBM-bound early stages run beside the other's MFMA-bound late
-    # ones (free-running pipelines keep their offset; the delay is paid for inside the K timed steps)
-    stagger_ms = float(os.environ.get("YOLO_BENCH_STAGGER_MS", "0"))
     with torch.no_grad():
         for i in range(args.warmup):
             step(i)
@@ -390,8 +386,6 @@ def main():
         t0 = time.perf_counter()
         for i in range(args.warmup, total_steps):
             dets, counts = step(i)
-            if stagger_ms > 0 and i == args.warmup:
-                time.sleep(stagger_ms * 1e-3)
         sync_all()
         dt = time.perf_counter() - t0
     # conv-family time of a step, measured: HIP events bracket every launch list on the stream it is launched on; the lists of

@@ -1011,12 +1011,12 @@ class StreamedPlan:
         every register of every CU it lands on).  It pays where the launches are MFMA-dense and about one round of workgroups
         long - the chip then runs against its socket power limit and half the CUs hold a higher clock.
         Measured images/s, split vs shared: SPP-640 bs=32 +2.6 %, bs=16 +1.5 %, bs=64 -0.7 %; SPP-416 bs=32 -9 %; tiny-416 -2.5 %,
-        MobileNetV2-tiny -4.6 % (small launches).  "auto" therefore splits between 16 and 48 GFLOP per launch of a sub-batch
-        (SPP-640 at 8..16 images per stream); whole XCDs per stream ("xcd") lose 1 %.
+        MobileNetV2-tiny -4.6 % (small launches).  "auto" therefore splits between 16 and 96 GFLOP per launch of a pipeline
+        (SPP-640 at 8..32 images per stream); whole XCDs per stream ("xcd") lose 1 %.
         YOLO_CU_PARTITION = auto (default) | split | xcd | off."""
         mode = os.environ.get("YOLO_CU_PARTITION", "auto")
-        if mode == "auto":
-            mode = "split" if 16e9 <= flops_per_launch < 48e9 else "off"
+        if mode == "auto":      # (round 3: the whole-batch pipelines of SPP-640 x 32 - 69 GFLOP per launch - gain 1.0 % too: profiles/r03_cu_partition_ab.txt)
+            mode = "split" if 16e9 <= flops_per_launch < 96e9 else "off"
         n_cu = torch.cuda.get_device_properties(device).multi_processor_count
         n_xcd = 8
         per = n_cu // n_xcd
