@@ -76,7 +76,7 @@ def host_cores() -> int:
 
 def power_sample(step_fn, seconds: float = 2.0):
     """Socket power and shader clock while the timed workload keeps running (OUTSIDE the timed region): rocm-smi read about
-    twice a second with ~0.3 s of steps queued ahead of every read.  DESIGN.md 3.1k: the MFMA-dense layers run against the
+    twice a second with ~0.3 s of steps queued ahead of every read.  DESIGN.md 3.2a: the MFMA-dense layers run against the
     socket power limit, which is what holds roofline.frac where it is.  None when rocm-smi is not there."""
     import re
     import shutil

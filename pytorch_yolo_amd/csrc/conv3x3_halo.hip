@@ -3,7 +3,7 @@
 //
 // Why a second kernel: the gather implicit-GEMM stages the pixel operand once PER FILTER TAP (9x the input
 // bytes through the L2 -> LDS path).  On the big maps (>= 80x80) that path, not the matrix pipe, is the
-// limiter (loads-only 0.095 ms vs MFMA-only 0.10 ms vs 0.31 ms total for 64->128 @160^2).
+// limiter (profiles/r02_DESIGN_lab_notebook.md §3.1a: loads-only 0.095 ms vs MFMA-only 0.10 ms vs 0.31 ms total for 64->128 @160^2).
 // Here a block owns a TH x TW output tile of ONE image and stages the (TH+2) x (TW+2) input halo tile once per
 // cin chunk; the nine taps then read it at shifted LDS rows.  Only the weights are streamed per tap.
 //

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NP)) void conv_igemm_bf16
   static_assert(!SPLITK || (FAST && LDS_EPI && MFMA16 && !DECODE), "split-K: 16x16x32 path with the LDS epilogue");
   constexpr int NW = WAVES_M * WAVES_N;
   // NP > 0: NP extra LOADER waves issue every LDS-DMA of the block; the NW MFMA waves only read LDS and multiply
-  // (an LDS-DMA costs its issuing wave 60-180 cycles: ablation in DESIGN.md 3.1c).  NL = number of loader waves.
+  // (an LDS-DMA costs its issuing wave 60-180 cycles: ablation: profiles/r02_DESIGN_lab_notebook.md 3.1c).  NL = number of loader waves.
   constexpr int NL = NP > 0 ? NP : NW;
   static_assert(NP == 0 || (NS <= 3 && FAST && NP % 2 == 0), "loader waves: 2- or 3-stage ring, FAST path");
   static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves");

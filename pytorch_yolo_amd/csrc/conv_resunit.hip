@@ -87,7 +87,7 @@ __global__ __launch_bounds__(512) void resunit_kernel(const ResUnitArgs ra) {
 
   // C = 64: the residual (= the tile's own x pixels) is picked out of the phase-A staging while it is still in LDS —
   // both K steps of x are resident then — instead of being re-read from global in the epilogue, where four
-  // dependent load -> add -> store rounds per wave were half of this kernel's time (ablation in DESIGN.md 3.1d)
+  // dependent load -> add -> store rounds per wave were half of this kernel's time (ablation: profiles/r02_DESIGN_lab_notebook.md 3.1d)
   ResPrefetch<MI, TM> rp;
   constexpr bool RES_FROM_LDS = C == 64;
 

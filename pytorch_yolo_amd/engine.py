@@ -31,7 +31,7 @@ from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SWISH, DT_BF1
                    OP_CONV1_POOL, OP_CONV_POOL, OP_MAXPOOL_F32, OP_MBCONV, OP_SHUFFLE, OP_HEAD_DECODE, OP_MAXPOOL, OP_RESUNIT, OP_SPP,
                    OP_STEM, YoloOp)
 
-# which residual-unit widths run as ONE launch (bit mask of C: 64 | 128 | 256); see DESIGN.md §3.1d for the
+# which residual-unit widths run as ONE launch (bit mask of C: 64 | 128 | 256); see DESIGN.md §3.3 for the
 # measurements behind the default (round 3, three interleaved rounds on one box, images/s: 64 -> 6,180; 64 | 128 -> 6,222;
 # 64 | 128 | 256 -> 6,022: profiles/r03_fuse_resunit_ab.txt).  YOLO_FUSE_RESUNIT overrides it (tuning only).
 FUSE_RESUNIT_DEFAULT = 64 | 128
@@ -649,7 +649,7 @@ class Plan:
                     d.res_c_total = self.rec.c_in          # real input channels (x pointer is patched per call)
                 # split-K launches are OFF by default: correct and deterministic (tests), but on MI355X the cross-XCD exchange
                 # of the fp32 partials (agent-scope accesses that bypass the per-XCD L2) costs more than the idle CUs it
-                # fills: 0.041 -> 0.13 ms on YOLOv3-tiny's 3x3 256 -> 512 layer at 13x13 x 32 (DESIGN.md 7)
+                # fills: 0.041 -> 0.13 ms on YOLOv3-tiny's 3x3 256 -> 512 layer at 13x13 x 32 (DESIGN.md Appendix A)
                 if op.kind == OP_CONV and os.environ.get("YOLO_SPLITK", "0") == "1":
                     sp, wb, nc = K.conv2d_splitk_plan(d, res is not None, aux is not None)
                     if sp >= 2:                            # few pixels, long K: split-K launch (yolo_conv2d_splitk_fwd)
@@ -1009,7 +1009,7 @@ class StreamedPlan:
         lies on XCD b % 8), so two layer lists really run side by side - one stream's HBM-bound phases (1x1 layers, epilogues)
         under the other's MFMA-dense ones - instead of time-slicing the workgroup slots of the whole chip (a 3x3 launch takes
         every register of every CU it lands on).  It pays where the launches are MFMA-dense and about one round of workgroups
-        long - the chip then runs against its socket power limit and half the CUs hold a higher clock (DESIGN.md 3.1k).
+        long - the chip then runs against its socket power limit and half the CUs hold a higher clock (DESIGN.md 3.2a, 3.7).
         Measured images/s, split vs shared: SPP-640 bs=32 +2.6 %, bs=16 +1.5 %, bs=64 -0.7 %; SPP-416 bs=32 -9 %; tiny-416 -2.5 %,
         MobileNetV2-tiny -4.6 % (small launches).  "auto" therefore splits between 16 and 96 GFLOP per launch of a pipeline
         (SPP-640 at 8..32 images per stream); whole XCDs per stream ("xcd") lose 1 %.

@@ -4,7 +4,7 @@
     python tools/power_probe.py [--half] [--seconds 6] n,h,w,cin,cout,k,stride[,res]
 
 Launches the layer in a loop for the given time and samples `rocm-smi --showpower --showclocks` from a helper process
-twice a second; prints the layer's average time and the samples.  (Evidence for DESIGN.md 3.1k: the MFMA-dense layers run
+twice a second; prints the layer's average time and the samples.  (Evidence for DESIGN.md 3.2a: the MFMA-dense layers run
 against the socket power limit, not against an issue or memory limit.)"""
 import os
 import re
