@@ -48,12 +48,16 @@ struct ConvArgs {
   int splits;
   float* ws;
   int* cnt;
-  int debug;    // YOLO_CONV_DEBUG, tuning / ablation only (results are wrong with bits 1..8 set):
-                //   1 no pixel DMA   2 no weight DMA   4 no MFMA   8 no epilogue   16 no LDS-staged epilogue
-                //   32 no halo kernel   128 no 128x256 tiles   256 no loader waves   512 8-wave 256x256 tiles
-                //   1024 halo blocks of 256 couts   2048 32x32x16 MFMA in the gather kernel   8192 4-wave 128x128 / head tiles
-                //   16384 two-stage ring for the loader-wave tiles   32768 64x64 tiles for every tiny-grid 1x1 layer
-                //   65536 32x32x16 MFMA in the halo kernel
+  int debug;    // YOLO_CONV_DEBUG / yolo_set_tuning(1, .), timing ablations and A/B rules only (results are wrong with bits 1..8 set).
+                // Ablation bits every conv kernel understands:   1 no pixel DMA   2 no weight DMA   4 no MFMA   8 no epilogue
+                // Rule bits of the dispatcher (conv_igemm.hip):  16 no LDS-staged epilogue   32 no halo kernel   128 no 128x256 tiles
+                //   256 no loader waves   512 8-wave 256x256 tiles   2048 32x32x16 MFMA in the gather kernel   8192 4-wave 128x128 / head
+                //   tiles   16384 two-stage ring for the loader-wave tiles   32768 64x64 tiles for every tiny-grid 1x1 layer
+                //   4194304 two-stage 64x64 tiles;   halo kernel: 1024 blocks of 256 couts   65536 32x32x16 MFMA
+                // Kernel FAMILIES are selected by the other knob, YOLO_CONV_PP / yolo_set_tuning(2, .): 8 no halo kernel, 16 / 64 the
+                //   20x20-tile kernels always / never, 1024 / 2048 the streaming 1x1 never / always.  YOLO_RESUNIT_DEBUG (fused units):
+                //   8 no epilogue, 32 generic 16x16 kernel for C = 64, 64 / 128 the 20-pixel-wide tile kernels always / never,
+                //   512 one workgroup per CU, 1024 dump tile 0's intermediate (tools/dbg/ruw_tdump.py).
 #ifdef YOLO_STAMPS
   unsigned long long* stamps;   // diagnostic build only (tools/block_timeline.py): 4 words per workgroup
 #endif
