@@ -13,4 +13,10 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_
 echo write pass done
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kstats_${WL} -- python3 bench.py --workload $WL --steps 30 --warmup 5 --no-cpu-baseline --no-api --no-sustained > gpurun_out/kstats_${WL}_bench.json 2> gpurun_out/kstats_${WL}.err
 echo stats pass done
-find gpurun_out/pmc_${WL}_f gpurun_out/pmc_${WL}_w gpurun_out/kstats_${WL} -name "*.csv"
+find gpurun_out/pmc_${WL}_f gpurun_out/pmc_${WL}_w gpurun_out/kstats_${WL} -name "*.csv" | head -3
+if [ "$2" == "mfma" ]; then
+  rm -rf gpurun_out/pmc_${WL}_mfma
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_${WL}_mfma -- python3 bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --no-api --no-sustained > gpurun_out/pmc_${WL}_mfma.json 2> gpurun_out/pmc_${WL}_mfma.err
+  echo mfma pass done
+  find gpurun_out/pmc_${WL}_mfma -name "*.csv"
+fi
