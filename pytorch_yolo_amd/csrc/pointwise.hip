@@ -115,6 +115,57 @@ __global__ __launch_bounds__(256) void spp_kernel(bf16_t* __restrict__ buf, int 
   }
 }
 
+// Line-wide form for c % 64 == 0 (the shipped SPP: 512 channels on 20x20): one block = one image x 64 channels, i.e. whole
+// 128-byte lines of the NHWC buffer per pixel both ways (the 8-channel form above touches 16 of a line's 128 bytes per access:
+// rocprofv3 counted 100 MB fetched / 75 MB written for 13 + 39 MB).  Two LDS planes of hw x 128 B only; the radii grow from one
+// another, r4(x) = max(r2(x-2), r2(x+2)) and r6 from r4 likewise (positions clamped to the row: a clamped window stays inside the
+// true one and the pair still covers it), so a level's row maxima overwrite the plane the previous level no longer reads:
+//   B = r2(A) | out5 = V2(B), A = r4(B) | out9 = V4(A), B = r6(A) | out13 = V6(B)           (| = barrier)
+__global__ __launch_bounds__(512) void spp_lines_kernel(bf16_t* __restrict__ buf, int h, int w, int c) {
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  const int hw = h * w, ct = 4 * c, cg = c / 64;
+  u32x4* pa = reinterpret_cast<u32x4*>(lds_raw);     // [hw][8 chunks of 8 channels]
+  u32x4* pb = pa + hw * 8;
+  const long b = blockIdx.x / cg;
+  const int g = blockIdx.x % cg;
+  bf16_t* base = buf + b * hw * ct + g * 64;
+  const int items = hw * 8;
+  for (int i = threadIdx.x; i < items; i += 512)
+    pa[i] = bf16_sortable(*reinterpret_cast<const u32x4*>(base + (long)(i >> 3) * ct + 3 * c + (i & 7) * 8));
+  __syncthreads();
+  for (int i = threadIdx.x; i < items; i += 512) {
+    const int p = i >> 3, xx = p % w;
+    u32x4 m = pa[i];
+#pragma unroll
+    for (int r = 1; r <= 2; ++r) {
+      if (xx - r >= 0) m = pk_max(m, pa[i - r * 8]);
+      if (xx + r < w) m = pk_max(m, pa[i + r * 8]);
+    }
+    pb[i] = m;
+  }
+  __syncthreads();
+  auto level = [&](const u32x4* rows, u32x4* next, int rad, int slot) {
+    for (int i = threadIdx.x; i < items; i += 512) {
+      const int p = i >> 3, yy = p / w, xx = p - yy * w;
+      u32x4 m = rows[i];
+      for (int r = 1; r <= rad; ++r) {
+        if (yy - r >= 0) m = pk_max(m, rows[i - r * w * 8]);
+        if (yy + r < h) m = pk_max(m, rows[i + r * w * 8]);
+      }
+      *reinterpret_cast<u32x4*>(base + (long)p * ct + slot * c + (i & 7) * 8) = bf16_sortable(m);
+      if (next) {
+        const int lo = xx - 2 < 0 ? -xx : -2, hi = xx + 2 >= w ? w - 1 - xx : 2;
+        next[i] = pk_max(rows[i + lo * 8], rows[i + hi * 8]);
+      }
+    }
+  };
+  level(pb, pa, 2, 0);
+  __syncthreads();
+  level(pa, pb, 4, 1);
+  __syncthreads();
+  level(pb, nullptr, 6, 2);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Depthwise 3x3 (pad 1) + bias + activation, one thread = 8 channels of one output pixel, fp32 math.  (Reference form:
 // yolo_dwconv3x3_fwd launches the strip kernel below; YOLO_DWCONV_DEBUG=1 selects this one.)
@@ -274,6 +325,14 @@ extern "C" int yolo_channel_shuffle2_fwd(const void* a, const void* b, void* y, 
 
 extern "C" int yolo_spp_fwd(void* buf, int n, int h, int w, int c, yolo_stream_t s) {
   YOLO_REQUIRE(buf && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0, "spp: bad arguments");
+  const size_t lds_lines = (size_t)2 * h * w * 128;
+  static const bool no_lines = getenv("YOLO_SPP_NO_LINES") != nullptr;     // A/B knob: the 8-channel form for every shape
+  if (c % 64 == 0 && lds_lines <= 128 * 1024 && !no_lines) {
+    static const int attr = hipFuncSetAttribute((const void*)spp_lines_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    YOLO_REQUIRE(attr == hipSuccess, "spp: cannot raise the LDS limit");
+    hipLaunchKernelGGL(spp_lines_kernel, dim3((unsigned)(n * (c / 64))), dim3(512), lds_lines, (hipStream_t)s, (bf16_t*)buf, h, w, c);
+    return yolo_check_launch("yolo_spp_fwd");
+  }
   const size_t lds = (size_t)4 * h * w * 16;
   if (lds <= 64 * 1024) {
     hipLaunchKernelGGL(spp_kernel, dim3((unsigned)(n * (c / 8))), dim3(256), lds, (hipStream_t)s, (bf16_t*)buf, h, w, c);

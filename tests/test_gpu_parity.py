@@ -467,15 +467,17 @@ def test_maxpool21_kat():
     assert np.array_equal(got[0, 3].numpy(), load_golden("kat")["maxpool21"][0, 0])
 
 
-@pytest.mark.parametrize("h,w", [(20, 20), (13, 17), (4, 3), (72, 72)])
-def test_spp_exact(h, w):
+@pytest.mark.parametrize("h,w,c", [(20, 20, 24), (13, 17, 24), (4, 3, 24), (72, 72, 24),
+                                   # c % 64 == 0: spp_lines_kernel (whole 128-byte lines, radii grown from one another)
+                                   (20, 20, 128), (13, 17, 64), (4, 3, 64), (1, 1, 64), (22, 23, 192), (7, 1, 64), (1, 9, 64)])
+def test_spp_exact(h, w, c):
     from pytorch_yolo_amd import kernels as K
     from oracle.blocks import max_pool
-    c = 24
-    x = _bf16r(torch.randn(2, c, h, w))
-    buf = torch.zeros(2, h, w, 4 * c, dtype=torch.bfloat16, device=DEV)
+    x = _bf16r(torch.randn(3, c, h, w, generator=torch.Generator().manual_seed(h * 100 + w)))
+    x[0, 0, 0, 0] = float("-inf")                  # -inf inputs survive (padding is -inf too: nn.MaxPool2d)
+    buf = torch.zeros(3, h, w, 4 * c, dtype=torch.bfloat16, device=DEV)
     buf[..., 3 * c:] = _nhwc(x)
-    K.spp(buf, n=2, h=h, w=w, c=c)
+    K.spp(buf, n=3, h=h, w=w, c=c)
     got = _nchw(buf)
     want = torch.cat([max_pool(x, 5, 1), max_pool(x, 9, 1), max_pool(x, 13, 1), x], 1)
     assert torch.equal(got, want)
