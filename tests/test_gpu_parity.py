@@ -363,7 +363,8 @@ def test_fused_head_decode(n, h, w, cin, k, nc, act):
     torch.testing.assert_close(p.cpu(), ref, rtol=1e-4, atol=2e-4)
 
 
-@pytest.mark.parametrize("n,cin,h,w", [(2, 3, 64, 64), (1, 3, 70, 106), (1, 1, 37, 50), (2, 3, 192, 352)])
+@pytest.mark.parametrize("n,cin,h,w", [(2, 3, 64, 64), (1, 3, 70, 106), (1, 1, 37, 50), (2, 3, 192, 352), (1, 3, 2, 2), (1, 3, 33, 17),
+                                        (3, 3, 416, 416), (40, 3, 96, 96)])
 def test_fused_stem(n, cin, h, w):
     """yolo_stem_fwd (conv3x3/s1 cin->32 + conv3x3/s2 32->64 from the float32 NCHW batch in one launch) against fp32
     torch on the same bf16-rounded operands (intermediate rounded to bf16 like the two-kernel path stores it);
@@ -390,6 +391,23 @@ def test_fused_stem(n, cin, h, w):
     ref = F.leaky_relu(F.conv2d(mid, _bf16r(w2), b2, stride=2, padding=1), 0.1)
     torch.testing.assert_close(_nchw(y[..., out_co:out_co + 64]), ref, rtol=1e-2, atol=2e-2)
     assert torch.all(y[..., :out_co] == -77.0) and torch.all(y[..., out_co + 64:] == -77.0)
+    # and what the two launches it replaces give (first-layer kernel -> bf16 intermediate -> stride-2 conv).  Not bit for bit:
+    # the fused kernel sums conv1's 27 products in another order (K = 48 instead of K = 80 inside the MFMA) and the stride-2 conv's
+    # 288 in the order of its own tile shape, so an intermediate value can land on the neighbouring bf16 and an output likewise
+    import ctypes as C
+    from pytorch_yolo_amd._lib import check, load
+    mid_dev = torch.empty(n, h, w, 32, dtype=torch.bfloat16, device=DEV)
+    y2 = torch.full_like(y, -77.0)
+    xd, w1d, b1d = x.to(DEV), w1p.to(DEV), b1p.to(DEV)
+    d1 = K.conv_desc(n=n, h=h, w=w, cin=8, in_c_total=8, in_c_offset=0, cout=32, out_c_total=32, out_c_offset=0, ksize=3, stride=1,
+                     act=ACT_LEAKY01, kpad=kpad1, cout_pad=32)
+    check(load().yolo_conv1_nchw_f32_fwd(xd.data_ptr(), cin, w1d.data_ptr(), b1d.data_ptr(), mid_dev.data_ptr(), C.byref(d1),
+                                         K.stream_ptr()), "conv1")
+    K.conv2d(mid_dev, w2p.to(DEV), b2p.to(DEV), y2, d)
+    torch.cuda.synchronize()
+    ya, yb = y.float(), y2.float()
+    torch.testing.assert_close(ya, yb, rtol=2 ** -6, atol=2e-2)
+    assert float((ya != yb).float().mean()) < 0.05
 
 
 @pytest.mark.parametrize("cin,cout,h,w", [(3, 16, 64, 96), (3, 32, 32, 32), (1, 16, 38, 50)])
