@@ -31,17 +31,21 @@ struct StemArgs {
   const float* b2;
   bf16_t* y;            // NHWC view
   int n, h, w, cin_real, ho, wo, out_c_total, out_c_offset, kpad1, kpad2, act;
-  int debug;            // timing ablations (YOLO_STEM_DEBUG): 1 no input loads, 2 no phase A, 4 no phase B, 8 no stores
+  int debug;            // timing ablations (YOLO_STEM_DEBUG): 1 no input loads, 2 no phase A, 4 no phase B (stem_kernel only), 8 no
+                        // stores, 64 producer waves alone (stem2_kernel only)
   unsigned long long* stamps;   // diagnostic build only (-DYOLO_STAMPS, tools/stem_timeline.py)
 };
 
 // Diagnostic build only: the first lane of wave 0 (producer) and wave 4 (consumer) of every workgroup records s_memrealtime
-// (100 MHz) at four points of steps 8..23: [workgroup][role][step - 8][point]
+// (100 MHz) at up to twelve points of steps 8..23: [workgroup][role][step - 8][point]
 #ifdef YOLO_STAMPS
 #define STEM_STAMP(role, t, k)                                                                                                 \
   do {                                                                                                                         \
     if (a.stamps && lane == 0 && (wave & 3) == 0 && (t) >= 8 && (t) < 24)                                                      \
-      a.stamps[(((size_t)blockIdx.x * 2 + (role)) * 16 + ((t)-8)) * 4 + (k)] = __builtin_amdgcn_s_memrealtime();              \
+    {                                                                                                                        \
+      a.stamps[(((size_t)blockIdx.x * 2 + (role)) * 16 + ((t)-8)) * 12 + (k)] = __builtin_amdgcn_s_memrealtime();            \
+      if ((k) == 0) a.stamps[(((size_t)blockIdx.x * 2 + (role)) * 16 + ((t)-8)) * 12 + 10] = __builtin_amdgcn_s_memtime();    \
+    }                                                                                                                        \
   } while (0)
 #else
 #define STEM_STAMP(role, t, k)
@@ -319,6 +323,9 @@ __global__ __launch_bounds__(512) void stem_kernel(const StemArgs a) {
 // hit sixteen different 16-byte bank groups), so every LDS address is a per-lane base plus a compile-time offset.
 // conv1 sums its 27 products in another order than the K = 80 kernels (fp32 accumulation inside the MFMA): `mid` can differ from
 // theirs by one bf16 ulp on a few elements.
+// Measured (32 images 640x640): 0.285 -> 0.209 ms.  tools/stem_timeline.py (stamps build): a step takes ~2.1 us, the producers'
+// conv1 1.6 us of it (1.2 us with the consumers parked, 0.2 us per block of 3 MFMAs + 36 VALU + 7 LDS instructions), the consumers'
+// 36 MFMAs + epilogue 1.2-1.3 us: both roles run at about twice their issue cost and the producers are the longer pole.
 template <bool LEAKY>
 __global__ __launch_bounds__(512) void stem2_kernel(const StemArgs a) {
   constexpr int TW = 16, TH = 8;                                     // output tile
@@ -461,11 +468,19 @@ __global__ __launch_bounds__(512) void stem2_kernel(const StemArgs a) {
     }
     wait_lds();
     __builtin_amdgcn_s_barrier();
-    // step t: conv1 of tile t + 1 (input buffer (t+1)&1 -> mid buffer (t+1)&1) while the consumers work on tile t; then the halo of
-    // tile t + 2 (in registers since step t - 1) goes to input buffer t&1, which conv1 of tile t read one step ago, and the loads of
-    // tile t + 3 are issued
+    // step t: the halo of tile t + 2 (in registers since the start of step t - 1) goes to input buffer t&1, which conv1 of tile t
+    // read one step ago, and the loads of tile t + 3 are issued into the freed registers; then conv1 of tile t + 1 (input buffer
+    // (t+1)&1 -> mid buffer (t+1)&1) while the consumers work on tile t.  (Two register sets, loads two steps ahead, ran slower:
+    // the compiler's wait before the older set's first use - vmcnt(6) with 18 loads in flight - also waits for three of the loads
+    // just issued.)
     for (int t = -1; t < count; ++t) {
       STEM_STAMP(0, t, 0);
+      if (t + 2 < count) commit(s_in + (t & 1) * IN_B);
+      if (t + 3 < count) {
+        advance(ftx, fty, fb);
+        fetch(fb, fty, ftx);
+      }
+      STEM_STAMP(0, t, 2);
       if (t + 1 < count) {
         const char* const in = s_in + ((t + 1) & 1) * IN_B;
         char* const mid = s_mid + ((t + 1) & 1) * MID_B;
@@ -506,6 +521,7 @@ __global__ __launch_bounds__(512) void stem2_kernel(const StemArgs a) {
             }
             f32x16& nxt = accs[(sl + 1) & 1];
             const f32x16& cur = accs[sl & 1];
+            STEM_STAMP(0, t, 4 + sl);
             if (sl + 2 < A_SLOTS) reads(sl + 2, xf[(sl + 2) % 3]);
             if (more) nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1[0], __builtin_bit_cast(bf16x8, xf[(sl + 1) % 3][0]), bias1, 0, 0, 0);
             put(cur, sl, 0, inside);
@@ -526,12 +542,6 @@ __global__ __launch_bounds__(512) void stem2_kernel(const StemArgs a) {
         advance(ptx, pty, pb);
       }
       STEM_STAMP(0, t, 1);
-      if (t + 2 < count) commit(s_in + (t & 1) * IN_B);
-      STEM_STAMP(0, t, 2);
-      if (t + 3 < count) {
-        advance(ftx, fty, fb);
-        fetch(fb, fty, ftx);
-      }
       wait_lds();
       STEM_STAMP(0, t, 3);
       __builtin_amdgcn_s_barrier();
@@ -567,8 +577,9 @@ __global__ __launch_bounds__(512) void stem2_kernel(const StemArgs a) {
     // One step: the 36 MFMAs of a tile from mid buffer P (TAPS), and activation -> staging -> stores of the PREVIOUS tile from the
     // other accumulator set (EPI).  The order is pinned in the source - per tap: the next tap's two LDS reads, four MFMAs, one eighth
     // of the activation work, sched_barrier - because left alone the scheduler issues all MFMAs first and the epilogue behind them.
-    auto step = [&](auto parity, auto do_taps, auto do_epi) {
+    auto step = [&](auto parity, auto do_taps, auto do_epi, int tstamp) {
       constexpr int P = decltype(parity)::value;
+      (void)tstamp;
       constexpr bool TAPS = decltype(do_taps)::value, EPI = decltype(do_epi)::value;
       auto row = [&](int tap) {
         const int dh = tap / 3, dw = tap - 3 * dh;
@@ -583,6 +594,7 @@ __global__ __launch_bounds__(512) void stem2_kernel(const StemArgs a) {
       }
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
+        if (TAPS && tap % 3 == 0) STEM_STAMP(1, tstamp, 4 + tap / 3);
         if (TAPS) {
           if (tap < 8)
 #pragma unroll
@@ -600,6 +612,7 @@ __global__ __launch_bounds__(512) void stem2_kernel(const StemArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (TAPS) STEM_STAMP(1, tstamp, 7);
       if (EPI) {                                             // staging [32 pixels][64 couts] -> 16 B per lane, 128 B per pixel
         const int ox0 = tx * TW, oy0 = ty * TH;
         const uint32_t tile_off = (uint32_t)(((b * a.ho + oy0) * a.wo + ox0) * a.out_c_total) * 2u;
@@ -621,27 +634,31 @@ __global__ __launch_bounds__(512) void stem2_kernel(const StemArgs a) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();                            // step -1: the producers' first conv1
     // step t: the taps of tile t with the epilogue of tile t - 1
-    step(P0{}, std::true_type{}, std::false_type{});
+    step(P0{}, std::true_type{}, std::false_type{}, 0);
     wait_lds();
     __builtin_amdgcn_s_barrier();
+    if (a.debug & 64) {                                      // timing only: the producers alone
+      for (int t = 1; t < count; ++t) __builtin_amdgcn_s_barrier();
+      return;
+    }
     for (int t = 1; t < count; t += 2) {
       STEM_STAMP(1, t, 0);
-      step(P1{}, std::true_type{}, std::true_type{});
+      step(P1{}, std::true_type{}, std::true_type{}, t);
       STEM_STAMP(1, t, 1);
       wait_lds();
       STEM_STAMP(1, t, 3);
       __builtin_amdgcn_s_barrier();
       if (t + 1 < count) {
         STEM_STAMP(1, t + 1, 0);
-        step(P0{}, std::true_type{}, std::true_type{});
+        step(P0{}, std::true_type{}, std::true_type{}, t + 1);
         STEM_STAMP(1, t + 1, 1);
         wait_lds();
         STEM_STAMP(1, t + 1, 3);
         __builtin_amdgcn_s_barrier();
       }
     }
-    if ((count - 1) & 1) step(P0{}, std::false_type{}, std::true_type{});      // epilogue of accumulator set 1
-    else step(P1{}, std::false_type{}, std::true_type{});
+    if ((count - 1) & 1) step(P0{}, std::false_type{}, std::true_type{}, 0);      // epilogue of accumulator set 1
+    else step(P1{}, std::false_type{}, std::true_type{}, 0);
   }
 }
 
