@@ -17,7 +17,11 @@
 //               fp32, 16-byte buffer stores over whole 128-byte pixel rows, residual rows requested three pairs ahead.
 // Per tile the CU moves 62 KB in + 51 KB out (+ 51 KB of residual from L2) for 1,024 MFMAs: 0.93 GB per 32 images of 320x320, a
 // floor of ~0.17 ms at 5.5 TB/s.  Measured 0.318 ms (the persistent 16x16-tile kernel of conv_resunit.hip: 0.365 ms): a workgroup
-// is a load -> 1x1 -> 3x3 -> store chain and only two fit a CU.  Tried and dropped: a persistent form that fetches the next
+// is a load -> 1x1 -> 3x3 -> store chain and only two fit a CU.  Round 3 timeline (tools/ru_timeline.py 64 320, medians per tile):
+// halo DMA 3.0 us, 1x1 + intermediate 2.7, nine taps 2.5, epilogue 5.1 - 13.6 us for 2 us of MFMA work.  Shortening single links
+// of that chain moved the kernel by < 1.5 % each (same-box A/B): an epilogue per wave without workgroup barriers, residual rows 6 or
+// 9 patches ahead instead of 3, persistent workgroups that keep W1 / W2 in registers across tiles (needs an opaque per-trip lane
+// id, or the hoisted address constants spill).  Tried and dropped: a persistent form that fetches the next
 // tile's halo straight into MFMA operand registers during the epilogue (no LDS for x, 48 KB per workgroup) - 0.370 ms: in the
 // operand layout the four lanes that share a pixel row are 16 lanes apart, so a load instruction makes 64 separate 16-byte
 // requests where the LDS-DMA layout makes 16 of 64 bytes, and hoisted per-lane address constants pushed it into spills.
@@ -42,6 +46,17 @@ struct RU20Args {
   int stagger;          // resunit_t20w_kernel: start-up delay of the first round's second workgroups, in ~2k-cycle sleeps
 };
 
+// Diagnostic build only (-DYOLO_STAMPS, tools/ru_timeline.py): wave 0 of every workgroup records when it reached each phase
+// boundary (s_memrealtime, 100 MHz) - 8 words per workgroup in a buffer nothing else reads.
+#ifdef YOLO_STAMPS
+#define RU_STAMP(k)                                                                                                  \
+  do {                                                                                                               \
+    if (a.stamps && tid == 0) a.stamps[8 * (size_t)blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime();             \
+  } while (0)
+#else
+#define RU_STAMP(k)
+#endif
+
 __global__ __launch_bounds__(256, 2) void resunit64_t20_kernel(const RU20Args ra) {
   constexpr int RD = 3;                                  // residual rows in flight in the epilogue (patch pairs ahead)
   __shared__ __attribute__((aligned(16))) char smem[2 * kBuf];
@@ -62,6 +77,7 @@ __global__ __launch_bounds__(256, 2) void resunit64_t20_kernel(const RU20Args ra
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw1 = __builtin_amdgcn_make_buffer_rsrc((void*)ra.w1, 0, ra.w1_bytes, 0x00020000);
 
+  RU_STAMP(0);
   // ---- the x halo: piece (it * 4 + wave) = LDS rows [16 piece, +16); lane -> (row lane >> 2, physical slot lane & 3)
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
@@ -115,6 +131,7 @@ __global__ __launch_bounds__(256, 2) void resunit64_t20_kernel(const RU20Args ra
 #pragma unroll
     for (int i = 0; i < 2; ++i) acc1[it][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   wait_vmcnt<0>();                                         // my own DMA pieces (and W1) have landed: nobody else's rows are read here
+  RU_STAMP(1);
   static_for<2>([&](auto kcc) {
     constexpr int kc = decltype(kcc)::value;
     static_for<8>([&](auto itc) {
@@ -157,6 +174,7 @@ __global__ __launch_bounds__(256, 2) void resunit64_t20_kernel(const RU20Args ra
   }
   wait_lds();
   __builtin_amdgcn_s_barrier();                            // chunk image 0 now holds the whole intermediate halo
+  RU_STAMP(2);
 
   // ---- phase B: the nine taps
   const int dy = c16 >> 2, dx = c16 & 3;
@@ -223,6 +241,7 @@ __global__ __launch_bounds__(256, 2) void resunit64_t20_kernel(const RU20Args ra
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("s_nop 15\n\ts_nop 15");
 #endif
+    RU_STAMP(3);
     if (a.debug & 8) return;
 
     // ---- epilogue: pair r = patches 2 r (waves 0, 1) and 2 r + 1 (waves 2, 3)
@@ -259,6 +278,7 @@ __global__ __launch_bounds__(256, 2) void resunit64_t20_kernel(const RU20Args ra
   };
   if (pg == 0) run(std::integral_constant<int, 0>{});
   else run(std::integral_constant<int, 1>{});
+  RU_STAMP(4);
 }
 
 
@@ -302,17 +322,6 @@ struct RUW {
   static_assert(2 * SLAB <= LDS_B, "the epilogue slabs live in the image buffers");
   static_assert(LDS_B <= 80 * 1024, "two workgroups per CU");
 };
-
-// Diagnostic build only (-DYOLO_STAMPS, tools/ru_timeline.py): wave 0 of every workgroup records when it reached each phase
-// boundary (s_memrealtime, 100 MHz) - 8 words per workgroup in a buffer nothing else reads.
-#ifdef YOLO_STAMPS
-#define RU_STAMP(k)                                                                                                  \
-  do {                                                                                                               \
-    if (a.stamps && tid == 0) a.stamps[8 * (size_t)blockIdx.x + (k)] = __builtin_amdgcn_s_memrealtime();             \
-  } while (0)
-#else
-#define RU_STAMP(k)
-#endif
 
 template <int CMID, int TPH>
 __global__ __launch_bounds__(256, 2) void resunit_t20w_kernel(const RU20Args ra) {

@@ -41,6 +41,15 @@ torch.cuda.synchronize()
 s = stamps.cpu().numpy()
 s = s[s[:, 0] > 0]
 t0 = s[:, 0].min()
+if c == 64:      # resunit64_t20_kernel: 0 start, 1 halo landed, 2 intermediate written + barrier, 3 nine taps done, 4 epilogue done
+    us = (s[:, :5] - s[:, :1]) / 100.0
+    names = ["halo DMA (issue + wait)", "1x1 + intermediate + barrier", "nine taps", "epilogue"]
+    print(f"C=64 {hw}x{hw} n={n}: {len(s)} workgroups")
+    for k, nm in enumerate(names):
+        dur = us[:, k + 1] - us[:, k]
+        print(f"  {nm:30s} median {np.median(dur):6.2f} us   p10 {np.percentile(dur, 10):6.2f}   p90 {np.percentile(dur, 90):6.2f}")
+    print(f"  whole workgroup                median {np.median(us[:, 4]):6.2f} us")
+    sys.exit(0)
 us = (s[:, :6] - t0) / 100.0
 names = ["first x chunk", "x chunks x W1", "t write", "nine taps", "epilogue"]
 print(f"C={c} {hw}x{hw} n={n}: {len(s)} workgroups, span {us[:, 5].max():.1f} us")

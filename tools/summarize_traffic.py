@@ -20,7 +20,7 @@ def load(path, counter):
         k = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
         k = re.sub(r"yolo_conv::", "", k)
         k = ("conv kernels (conv_igemm_bf16 incl. head+decode / conv3x3_t20 / conv1x1_stream / conv3x3_halo / resunit / stem)"
-             if re.search(r"conv_igemm|conv3x3_halo|conv3x3_t20|conv3x3s2_t20|conv1x1_stream|conv1_nchw|resunit\w*_kernel|stem_kernel", k) else k.split("(")[0][:60])
+             if re.search(r"conv_igemm|conv3x3_halo|conv3x3_t20|conv3x3s2_t20|conv1x1_stream|conv1_nchw|resunit\w*_kernel|stem2?_kernel", k) else k.split("(")[0][:60])
         per[k] = per.get(k, 0.0) + float(r["Counter_Value"])
         n[k] += 1
     return per, n
