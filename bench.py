@@ -333,7 +333,7 @@ def main():
         calls[0] += 1
         tm = ev[i] if timed else None
         if gatherer is None:
-            plan.launch_detect(x, io, ps, nms_out, CONF_THRES, NMS_THRES, timing=tm, join=False, whole_batch=whole)
+            plan.launch_detect(x, io, ps, nms_out, CONF_THRES, NMS_THRES, timing=tm, join=False, whole_batch=whole, cu_partition=True)
             return nms_out[0], nms_out[2]
         plan.launch_detect(x, io, ps, nms_out, CONF_THRES, NMS_THRES, timing=tm, join=False, whole_batch=whole,
                            after_nms=gatherer.begin(nms_out))
@@ -459,7 +459,7 @@ def main():
                                 else f"{n_streams} x sub-batches of {bs // n_streams} of every step")
         cfg["hip_hw_queues"] = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
         if n_streams > 1:
-            used = plan._full_streams if whole else plan.pipe_streams
+            used = (plan._full_streams or plan.streams) if whole else plan.pipe_streams
             cfg["cu_partition"] = "half of every XCD per stream" if type(used[0]).__name__ == "ExternalStream" else "off (streams share the chip)"
         if sharded:
             cfg["rccl_ranks"], cfg["backend"] = dist.get_world_size(), backend

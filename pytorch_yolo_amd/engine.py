@@ -1090,9 +1090,15 @@ class StreamedPlan:
         return len(self.streams)
 
     def launch_detect(self, x, io, ps, nms_out, conf_thres, nms_thres, timing=None, join=True, after_nms=None, whole_batch=False,
-                      wait_for=None):
+                      wait_for=None, cu_partition=False):
         """``wait_for``: an event every pipeline of this call waits for before its first launch (pipelined calls do not wait for
         the calling stream: pass the event that says ``x`` is ready when another stream produced it).
+
+        ``cu_partition=True`` (whole-batch pipelines only): each pipeline launches on a stream that owns half of every XCD's CUs
+        when ``_make_streams`` finds the launches in the range where that pays (+0.4..1 % on SPP-640 x 32).  Opt-in, for loops that
+        only queue launches (bench.py): HIP creates CU-masked streams as BLOCKING streams, so every operation on the default stream
+        between two calls - the event that says ``x`` is ready, an H2D copy of the next batch - is a barrier between the
+        pipelines, and each of them then has half the chip: ``detect_stream()`` fell from 6,190 to 3,850 images/s with it.
 
         ``whole_batch=True`` (pipelined calls only): this call's WHOLE batch goes down ONE pipeline and successive calls
         alternate between the pipelines - two batches in flight instead of two halves of one.  The launches are twice as large
@@ -1114,9 +1120,10 @@ class StreamedPlan:
             if self._full is None:                           # one whole-batch plan per pipeline, built on first use
                 with torch.cuda.device(self.device):
                     self._full = [self._make_plan(self.bs) for _ in self.streams]
+            if cu_partition and self._full_streams is None:
                 made = self._make_streams(len(self.streams), self.device, self._full[0].conv_flops() / max(1, self._full[0].n_ops))
                 self._full_streams = made if type(made[0]).__name__ == "ExternalStream" else self.streams
-            streams = self._full_streams
+            streams = self._full_streams if cu_partition else self.streams
             k = self._batches % len(streams)
             self._batches += 1
             work = [(k, self._full[k], streams[k], 0, self.bs)]

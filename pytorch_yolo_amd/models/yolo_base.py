@@ -235,7 +235,8 @@ class YOLOBase(nn.Module):
         """``detect()`` over a stream of equally shaped batches with the GPU kept busy: a generator that yields, in order, the
         reference-style ``list[Tensor[n,7] | None]`` of every batch - batch k's list after batch k+S-1 has been launched (S = the
         plan's pipelines, 2 by default).  Successive batches alternate between the pipelines (``launch_detect(whole_batch=True)``):
-        no host sync per batch except the count read-back of the batch being handed out, which by then has left the GPU.
+        no host sync per batch except the count read-back of the batch being handed out, which by then has left the GPU.  The
+        pipelines share the chip (no CU partition: ``launch_detect(cu_partition=...)`` says why).
         SPP-640 x 32: ~6,000 images/s against ~4,700 for back-to-back ``detect()`` calls (bench.py)."""
         from ..utils.utils import nms_capacity, split_detections
         if self.training:

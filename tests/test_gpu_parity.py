@@ -2047,6 +2047,9 @@ def test_detect_stream_yields_every_batch_in_order():
                     if a is not None:
                         assert torch.equal(a, b)
     assert sum(d is not None for w in want for d in w) > 0
+    # the API pipelines must not run on CU-masked streams: HIP creates those as blocking streams, and the default-stream operations of
+    # a serving loop (the "x is ready" event, the H2D copies above) would then serialise the two pipelines on half the chip each
+    assert model.plan_for(host[0].to(DEV))._full_streams is None
     def idle():      # nothing of a dropped generator may still be running: its output ring goes back to the allocator
         plan = model.plan_for(host[0].to(DEV))
         sts = list(plan.streams) + list(plan._full_streams or []) + [plan._nms_stream]
