@@ -47,7 +47,7 @@ static_assert(2 * 32 * kV2Pitch <= 2 * kHaloB, "epilogue buffers reuse the halo 
 
 // Epilogue shared by the 4-wave forms (conv3x3_t20v2_kernel, conv3x3s2_t20_kernel): acc[i][jj] = couts (32 wave + 16 i + 4 q ..+3) x
 // the 16 pixels of patch jj of the 20x20 output tile at (b, y0, x0); `smem` = 2 x 32 x kV2Pitch bytes the main loop no longer needs.
-template <int RD>
+template <int RD, bool LEAKY>
 __device__ __forceinline__ void t20v2_epilogue(const ConvArgs& a, char* smem, f32x4 (&acc)[2][25], int wave, int lane, int b, int y0, int x0, int n0) {
   constexpr int NP = 25;
   const YoloConvDesc& d = a.d;
@@ -62,7 +62,8 @@ __device__ __forceinline__ void t20v2_epilogue(const ConvArgs& a, char* smem, f3
   const bool floor0 = d.act == YOLO_ACT_RELU || d.act == YOLO_ACT_RELU6;
   const float slope = d.act == YOLO_ACT_LEAKY01 ? 0.1f : 1.f;
   const float hi_clamp = act_hi(d.act);
-  auto act4 = [&](f32x4 v) -> f32x4 {
+  auto act4 = [&](f32x4 v) -> f32x4 {                   // (LEAKY: the launcher's choice for LeakyReLU(0.1) layers - all of SPP's but the heads)
+    if (LEAKY) return leaky4(v);
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], floor0 ? 0.f : slope * v[e]), hi_clamp);
     return v;
@@ -140,7 +141,7 @@ __device__ __forceinline__ void t20v2_epilogue(const ConvArgs& a, char* smem, f3
 
 // XD: pixel fragments in flight (XD register sets in rotation, XD - 1 patches ahead of the MFMAs); RD: residual rows in flight
 // in the epilogue (RD patch pairs ahead of the pair being stored)
-template <int XD, int RD>
+template <int XD, int RD, bool LEAKY>
 __global__ __launch_bounds__(256, 2) void conv3x3_t20v2_kernel(const ConvArgs a) {
   constexpr int CT = 128, NW = 4, NP = 25, HPT = 8;
   __shared__ __attribute__((aligned(16))) char smem[kV2Lds];
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_t20v2_kernel(const ConvArgs a)
 
   // ---- epilogue (the final barrier of the loop has passed: the halo buffers are free; the weight prefetches of the two
   // steps beyond the end land in registers nobody reads)
-  t20v2_epilogue<RD>(a, smem, acc, wave, lane, b, y0, x0, n0);
+  t20v2_epilogue<RD, LEAKY>(a, smem, acc, wave, lane, b, y0, x0, n0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -291,7 +292,7 @@ static_assert(2 * 32 * kV2Pitch <= 2 * kPlaneB, "epilogue buffers reuse the plan
 // three planes in flight, 119 KB, one workgroup per CU) was measured for the grids that give a CU one workgroup anyway and is NOT
 // instantiated: 0.133 vs 0.125 ms on the 40 -> 20 layer at 32 images - with one wave per SIMD the MFMA stream itself, not the plane
 // fetch, is what stalls, and the gather kernel's 16-wave tiles do as well there; such grids stay with it (launch rule below).
-template <int XD, int RD, int NBUF>
+template <int XD, int RD, int NBUF, bool LEAKY>
 __global__ __launch_bounds__(256, 2) void conv3x3s2_t20_kernel(const ConvArgs a) {
   constexpr int NP = 25, PPW = 7, AHEAD = NBUF - 1;         // planes requested ahead of the one being multiplied
   static_assert(NBUF == 2 || NBUF == 4, "plane buffers");
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_t20_kernel(const ConvArgs a)
   if (a.debug & 8) return;
   wait_vmcnt<0>();                                     // (the dummy plane behind the last chunk is still landing in buffer 0)
   __builtin_amdgcn_s_barrier();
-  t20v2_epilogue<RD>(a, smem, acc, wave, lane, b, y0, x0, n0);
+  t20v2_epilogue<RD, LEAKY>(a, smem, acc, wave, lane, b, y0, x0, n0);
 }
 
 int launch_t20s2(const ConvArgs& a, hipStream_t s) {
@@ -448,7 +449,8 @@ int launch_t20s2(const ConvArgs& a, hipStream_t s) {
   const long grid = (long)a.d.n * ((a.d.ho + kT20 - 1) / kT20) * ((a.d.wo + kT20 - 1) / kT20) * b.n_tiles;
   if (grid > 0x7fffffffL) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv grid too large");
   if (pick_only("t20s2<400px x 128 couts, 4 waves, parity planes> grid %ld", grid)) return 0;
-  hipLaunchKernelGGL((conv3x3s2_t20_kernel<3, 3, 2>), dim3((unsigned)grid), dim3(256), 0, s, b);
+  if (a.d.act == YOLO_ACT_LEAKY01) hipLaunchKernelGGL((conv3x3s2_t20_kernel<3, 3, 2, true>), dim3((unsigned)grid), dim3(256), 0, s, b);
+  else hipLaunchKernelGGL((conv3x3s2_t20_kernel<3, 3, 2, false>), dim3((unsigned)grid), dim3(256), 0, s, b);
   return yolo_check_launch("yolo_conv2d_fwd(t20s2)");
 }
 
@@ -458,7 +460,8 @@ int launch_t20v2(const ConvArgs& a, hipStream_t s) {
   const long grid = (long)a.d.n * ((a.d.h + kT20 - 1) / kT20) * ((a.d.w + kT20 - 1) / kT20) * b.n_tiles;
   if (grid > 0x7fffffffL) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv grid too large");
   if (pick_only("t20v2<400px x 128 couts, 4 waves> grid %ld", grid)) return 0;
-  hipLaunchKernelGGL((conv3x3_t20v2_kernel<3, 3>), dim3((unsigned)grid), dim3(256), 0, s, b);
+  if (a.d.act == YOLO_ACT_LEAKY01) hipLaunchKernelGGL((conv3x3_t20v2_kernel<3, 3, true>), dim3((unsigned)grid), dim3(256), 0, s, b);
+  else hipLaunchKernelGGL((conv3x3_t20v2_kernel<3, 3, false>), dim3((unsigned)grid), dim3(256), 0, s, b);
   return yolo_check_launch("yolo_conv2d_fwd(t20v2)");
 }
 

@@ -147,6 +147,19 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // LDS operations of this wave have completed (data in registers / visible in LDS); vector-memory traffic keeps flying
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float raw_max(float x, float y) {      // v_max_f32 without fmaxf()'s operand canonicalisation
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+// LeakyReLU(0.1) of four values in 6 VALU instructions (2 v_pk_mul_f32 + 4 v_max_f32): the epilogues' data-independent
+// min(max(v, lo), hi) form costs a multiply, a select, a max and a min per value.  max(v, 0.1 v) keeps NaN (both operands NaN) and
+// +-inf like the generic form.
+__device__ __forceinline__ f32x4 leaky4(f32x4 v) {
+  const f32x2 lo = f32x2{v[0], v[1]} * 0.1f, hi = f32x2{v[2], v[3]} * 0.1f;
+  return f32x4{raw_max(v[0], lo[0]), raw_max(v[1], lo[1]), raw_max(v[2], hi[0]), raw_max(v[3], hi[1])};
+}
 __device__ __forceinline__ void wait_lds() {
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

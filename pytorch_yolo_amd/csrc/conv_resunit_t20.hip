@@ -57,6 +57,7 @@ struct RU20Args {
 #define RU_STAMP(k)
 #endif
 
+template <bool LEAKY>
 __global__ __launch_bounds__(256, 2) void resunit64_t20_kernel(const RU20Args ra) {
   constexpr int RD = 3;                                  // residual rows in flight in the epilogue (patch pairs ahead)
   __shared__ __attribute__((aligned(16))) char smem[2 * kBuf];
@@ -102,6 +103,7 @@ __global__ __launch_bounds__(256, 2) void resunit64_t20_kernel(const RU20Args ra
   const float slope = d.act == YOLO_ACT_LEAKY01 ? 0.1f : 1.f;
   const float hi_clamp = act_hi(d.act);
   auto act4 = [&](f32x4 v) -> f32x4 {
+    if (LEAKY) return leaky4(v);                           // (the launcher's choice for LeakyReLU(0.1): conv_common.h)
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], floor0 ? 0.f : slope * v[e]), hi_clamp);
     return v;
@@ -323,7 +325,7 @@ struct RUW {
   static_assert(LDS_B <= 80 * 1024, "two workgroups per CU");
 };
 
-template <int CMID, int TPH>
+template <int CMID, int TPH, bool LEAKY>
 __global__ __launch_bounds__(256, 2) void resunit_t20w_kernel(const RU20Args ra) {
   using G = RUW<CMID, TPH>;
   constexpr int PPW = G::PPW, IMG_B = G::IMG_B, NIMG = G::NIMG, NXC = G::NXC, NFW = G::NFW, NP = G::NP;
@@ -373,6 +375,7 @@ __global__ __launch_bounds__(256, 2) void resunit_t20w_kernel(const RU20Args ra)
   const float slope = d.act == YOLO_ACT_LEAKY01 ? 0.1f : 1.f;
   const float hi_clamp = act_hi(d.act);
   auto act4 = [&](f32x4 v) -> f32x4 {
+    if (LEAKY) return leaky4(v);                           // (the launcher's choice for LeakyReLU(0.1): conv_common.h)
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], floor0 ? 0.f : slope * v[e]), hi_clamp);
     return v;
@@ -686,7 +689,9 @@ int launch_ruw(const RU20Args& ra, bool force, hipStream_t s) {
   if (!force && !resunit_t20_applies(2 * CMID, d.n, d.h, d.w)) return 1;
   if (tiles > 0x7fffffffL) return 1;
   if (pick_only("resunit_t20w<C %d, %dpx x %d couts, 4 waves> grid %ld", 2 * CMID, 80 * TPH, 2 * CMID, tiles)) return 0;
-  hipLaunchKernelGGL((resunit_t20w_kernel<CMID, TPH>), dim3((unsigned)tiles), dim3(256), (ra.c.debug & 512) ? 40 * 1024 : 0, s, ra);   // bit 512: one workgroup per CU (diagnosis)
+  const size_t dyn = (ra.c.debug & 512) ? 40 * 1024 : 0;                    // bit 512: one workgroup per CU (diagnosis)
+  if (ra.c.d.act == YOLO_ACT_LEAKY01) hipLaunchKernelGGL((resunit_t20w_kernel<CMID, TPH, true>), dim3((unsigned)tiles), dim3(256), dyn, s, ra);
+  else hipLaunchKernelGGL((resunit_t20w_kernel<CMID, TPH, false>), dim3((unsigned)tiles), dim3(256), dyn, s, ra);
   return yolo_check_launch("yolo_resunit_fwd(t20w)");
 }
 
@@ -728,7 +733,8 @@ int launch_resunit_t20(const ConvArgs& c, const bf16_t* w1, const float* b1, int
   if (!force && !resunit_t20_applies(64, d.n, d.h, d.w)) return 1;
   if (tiles > 0x7fffffffL) return 1;
   if (pick_only("resunit64_t20<400px x 64 couts, 4 waves> grid %ld", tiles)) return 0;
-  hipLaunchKernelGGL(resunit64_t20_kernel, dim3((unsigned)tiles), dim3(256), 0, s, ra);
+  if (d.act == YOLO_ACT_LEAKY01) hipLaunchKernelGGL(resunit64_t20_kernel<true>, dim3((unsigned)tiles), dim3(256), 0, s, ra);
+  else hipLaunchKernelGGL(resunit64_t20_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, s, ra);
   return yolo_check_launch("yolo_resunit_fwd(t20)");
 }
 

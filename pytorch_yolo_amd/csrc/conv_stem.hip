@@ -51,13 +51,7 @@ struct StemArgs {
 #define STEM_STAMP(role, t, k)
 #endif
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef u32x4 u32x4_a8 __attribute__((aligned(8)));
-__device__ __forceinline__ float raw_max(float x, float y) {      // v_max_f32 without fmaxf()'s operand canonicalisation
-  float r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
-  return r;
-}
 
 template <bool LEAKY, int CIN>
 __global__ __launch_bounds__(512) void stem_kernel(const StemArgs a) {
