@@ -713,7 +713,10 @@ extern "C" int yolo_stem_fwd(const float* x_nchw, int cin_real, const void* w1_p
   hipStream_t st = (hipStream_t)s;
   const bool leaky = d.act == YOLO_ACT_LEAKY01;
   static const bool one_role = getenv("YOLO_STEM_ONE_ROLE") != nullptr;      // A/B knob: stem_kernel (round 2)
-  if (!one_role && cin_real == 3) {
+  // stem2_kernel addresses x and y through buffer descriptors with 32-bit byte offsets (and keeps pixel indices in int):
+  // batches whose input or output view reaches the out-of-range marker (~4 GB: 873 images of 640x640) take stem_kernel
+  const bool fits32 = (size_t)d.n * 3 * d.h * d.w * 4 < kOobOffset && (size_t)d.n * d.ho * d.wo * d.out_c_total * 2 < kOobOffset;
+  if (!one_role && cin_real == 3 && fits32) {
     const long tiles = (long)d.n * ((d.ho + 7) / 8) * ((d.wo + 15) / 16);
     if (tiles > 0x7fffffffL) return yolo_set_error(YOLO_E_UNSUPPORTED, "stem: too many tiles");
     const dim3 g((unsigned)(tiles < n_cu ? tiles : n_cu)), blk(512);     // one persistent block per CU
