@@ -252,6 +252,32 @@ def test_fused_residual_unit(n, h, w, c, use_aux):
         assert torch.equal(y, y3)
 
 
+@pytest.mark.parametrize("n,h,w,c", [(3, 200, 200, 64), (2, 320, 320, 128)])
+def test_fused_residual_unit_relu6(n, h, w, c):
+    """The fused-unit kernels' non-LeakyReLU instantiation (round 3: they are templated on the activation): ReLU6 on both convs
+    against fp32 torch."""
+    from pytorch_yolo_amd import kernels as K
+    from pytorch_yolo_amd._lib import ACT_RELU6
+    g = torch.Generator().manual_seed(c + 3)
+    x = torch.randn(n, c, h, w, generator=g)
+    w1 = torch.randn(c // 2, c, 1, 1, generator=g) * (2.0 / c) ** 0.5
+    b1 = torch.randn(c // 2, generator=g) * 0.1 + 0.3
+    w2 = torch.randn(c, c // 2, 3, 3, generator=g) * (2.0 / (c // 2 * 9)) ** 0.5 * 3.0          # (some outputs above 6)
+    b2 = torch.randn(c, generator=g) * 0.1
+    y = torch.empty(n, h, w, c, dtype=torch.bfloat16, device=DEV)
+    w1p, b1p, kpad1, cpad1 = K.pack_conv_weight(w1, b1, c)
+    w2p, b2p, kpad2, cpad2 = K.pack_conv_weight(w2, b2, c // 2)
+    d = K.conv_desc(n=n, h=h, w=w, cin=c // 2, in_c_total=c, in_c_offset=0, cout=c, out_c_total=c, out_c_offset=0, ksize=3, stride=1,
+                    act=ACT_RELU6, kpad=kpad2, cout_pad=cpad2)
+    assert K.resunit_form(c, n, h, w) == 3
+    K.resunit(_nhwc(x), w1p.to(DEV), b1p.to(DEV), w2p.to(DEV), b2p.to(DEV), y, d, kpad1, cpad1)
+    torch.cuda.synchronize()
+    mid = _bf16r(F.relu6(F.conv2d(_bf16r(x), _bf16r(w1), b1)))
+    pre = F.relu6(F.conv2d(mid, _bf16r(w2), b2, padding=1))
+    assert float((pre == 6.0).float().mean()) > 0.01 and float((pre == 0.0).float().mean()) > 0.1
+    torch.testing.assert_close(_nchw(y), pre + _bf16r(x), rtol=1e-2, atol=3e-2)
+
+
 @pytest.mark.parametrize("n,h,w,cin,hidden,cout,stride", [
     (2, 26, 30, 32, 32, 16, 1),       # first MobileNetV2 block: no expand conv
     (2, 40, 36, 16, 96, 24, 2),       # expand + stride 2, odd tile remainders
@@ -408,6 +434,36 @@ def test_fused_stem(n, cin, h, w):
     ya, yb = y.float(), y2.float()
     torch.testing.assert_close(ya, yb, rtol=2 ** -6, atol=2e-2)
     assert float((ya != yb).float().mean()) < 0.05
+
+
+def test_fused_stem_relu6_and_repeatable():
+    """stem2_kernel's non-LeakyReLU instantiation (ReLU6) against fp32 torch, partial tiles on both edges, and two launches give
+    the same bits (producer and consumer waves hand `mid` over through LDS with one barrier per tile)."""
+    from pytorch_yolo_amd import kernels as K
+    from pytorch_yolo_amd._lib import ACT_RELU6
+    n, h, w = 3, 150, 214
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(n, 3, h, w, generator=g)
+    w1 = torch.randn(32, 3, 3, 3, generator=g) * (2.0 / 27) ** 0.5 * 4.0
+    b1 = torch.randn(32, generator=g) * 0.1
+    w2 = torch.randn(64, 32, 3, 3, generator=g) * (2.0 / 288) ** 0.5 * 2.0
+    b2 = torch.randn(64, generator=g) * 0.1
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    w1p, b1p, kpad1, _ = K.pack_conv_weight(w1, b1, 8)
+    w2p, b2p, kpad2, cpad2 = K.pack_conv_weight(w2, b2, 32)
+    d = K.conv_desc(n=n, h=h, w=w, cin=32, in_c_total=32, in_c_offset=0, cout=64, out_c_total=64, out_c_offset=0, ksize=3, stride=2,
+                    act=ACT_RELU6, kpad=kpad2, cout_pad=cpad2)
+    ys = []
+    for _ in range(2):
+        y = torch.full((n, ho, wo, 64), -77.0, dtype=torch.bfloat16, device=DEV)
+        K.stem(x.to(DEV), 3, w1p.to(DEV), b1p.to(DEV), kpad1, w2p.to(DEV), b2p.to(DEV), y, d)
+        torch.cuda.synchronize()
+        ys.append(y)
+    assert torch.equal(ys[0], ys[1])
+    mid = _bf16r(F.relu6(F.conv2d(_bf16r(x), _bf16r(w1), b1, padding=1)))
+    ref = F.relu6(F.conv2d(mid, _bf16r(w2), b2, stride=2, padding=1))
+    assert float((mid == 6.0).float().mean()) > 0.001 and float((ref == 6.0).float().mean()) > 0.001
+    torch.testing.assert_close(_nchw(ys[0]), ref, rtol=1e-2, atol=3e-2)
 
 
 @pytest.mark.parametrize("cin,cout,h,w", [(3, 16, 64, 96), (3, 32, 32, 32), (1, 16, 38, 50)])
@@ -1690,6 +1746,45 @@ def test_t20_conv_kernel(case):
     diff = (y.float() - y0.float()).abs()
     assert float(diff.max()) <= 2 ** -6 * max(1.0, float(y0.float().abs().max())), "differs from the shipped kernels by more than 2 bf16 ulp"
     assert float((diff > 0).float().mean()) < 0.25   # same operands, another fp32 summation order: a minority of last-bit flips
+
+
+@pytest.mark.parametrize("stride,act", [(1, "leaky"), (1, "relu6"), (1, "none"), (2, "leaky"), (2, "relu6"), (2, "none")])
+def test_t20_epilogue_activations(stride, act):
+    """The 20x20-tile kernels are templated on LeakyReLU(0.1) (round 3: `leaky4`, 2 v_pk_mul + 4 v_max per four values) and keep the
+    data-independent min(max(v, lo), hi) form for the other activations: both instantiations of the stride-1 and the stride-2 kernel
+    (forced with yolo_set_tuning(2, 16)) against fp32 torch, and a NaN / +inf / -inf pre-activation (through the bias) comes out as
+    the reference's activation would give it (LeakyReLU / none: NaN stays NaN, both infinities stay; ReLU6 clamps the infinities)."""
+    from pytorch_yolo_amd import kernels as K
+    from pytorch_yolo_amd._lib import ACT_LEAKY01, ACT_NONE, ACT_RELU6, load
+    n, hw, cin, cout = 2, 40 * stride, 64, 128
+    g = torch.Generator().manual_seed(17 + stride)
+    x = torch.randn(n, cin, hw, hw, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    bias[3], bias[17], bias[cout - 2] = float("nan"), float("inf"), float("-inf")
+    wp, bp, kpad, cout_pad = K.pack_conv_weight(wt, bias, cin)
+    ho = (hw - 1) // stride + 1
+    y = torch.zeros(n, ho, ho, cout, dtype=torch.bfloat16, device=DEV)
+    d = K.conv_desc(n=n, h=hw, w=hw, cin=cin, in_c_total=cin, in_c_offset=0, cout=cout, out_c_total=cout, out_c_offset=0, ksize=3,
+                    stride=stride, act={"leaky": ACT_LEAKY01, "none": ACT_NONE, "relu6": ACT_RELU6}[act], kpad=kpad, cout_pad=cout_pad)
+    lib = load()
+    old = lib.yolo_set_tuning(2, 16)
+    try:
+        assert "t20" in K.conv2d_pick(d)                 # (the forced rule: the kernel under test really is the one launched)
+        K.conv2d(_nhwc(x), wp.to(DEV), bp.to(DEV), y, d)
+        torch.cuda.synchronize()
+    finally:
+        lib.yolo_set_tuning(2, old)
+    f = {"leaky": lambda t: F.leaky_relu(t, 0.1), "none": lambda t: t, "relu6": F.relu6}[act]
+    ref = f(F.conv2d(_bf16r(x), _bf16r(wt), bias, stride=stride, padding=1))
+    got = _nchw(y)
+    keep = [c for c in range(cout) if c not in (3, 17, cout - 2)]
+    torch.testing.assert_close(got[:, keep], ref[:, keep], rtol=1e-2, atol=1e-2)
+    if act == "relu6":        # (the clamp form maps a NaN to the lower bound; pinned for LeakyReLU / none, which SPP's layers use)
+        assert (got[:, 17] == 6.0).all() and (got[:, cout - 2] == 0.0).all()
+    else:
+        assert torch.isnan(got[:, 3]).all()
+        assert (got[:, 17] == float("inf")).all() and (got[:, cout - 2] == float("-inf")).all()
 
 
 T20S2_CASES = [
