@@ -160,6 +160,13 @@ __device__ __forceinline__ f32x4 leaky4(f32x4 v) {
   const f32x2 lo = f32x2{v[0], v[1]} * 0.1f, hi = f32x2{v[2], v[3]} * 0.1f;
   return f32x4{raw_max(v[0], lo[0]), raw_max(v[1], lo[1]), raw_max(v[2], hi[0]), raw_max(v[3], hi[1])};
 }
+// activation of four values under a wave-uniform branch: LeakyReLU(0.1) takes leaky4 (6 VALU), the others apply_act (16)
+__device__ __forceinline__ f32x4 act4(f32x4 v, int act) {
+  if (act == YOLO_ACT_LEAKY01) return leaky4(v);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act);
+  return v;
+}
 __device__ __forceinline__ void wait_lds() {
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -279,7 +286,8 @@ __device__ __forceinline__ void epilogue_lds(const ConvArgs& a, const f32x16 (&a
         const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + cbase + cl);
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[i][j][g4 * 4 + e] + bv[e], a.d.act);
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][g4 * 4 + e] + bv[e];
+        v = act4(v, a.d.act);
         *reinterpret_cast<f32x4*>(stg + row * pitch + col_off + cl * 4) = v;
       }
     }
@@ -301,9 +309,7 @@ __device__ __forceinline__ void epilogue_lds16(const ConvArgs& a, const f32x4 (&
       for (int j = 0; j < NI16; ++j) {
         const int row = j * 16 + c16 - row_lo;
         if (row < 0 || row >= nrows) continue;
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[2 * i + t][j][e] + bv[e], a.d.act);
+        const f32x4 v = act4(acc[2 * i + t][j] + bv, a.d.act);
         *reinterpret_cast<f32x4*>(stg + row * pitch + col_off + cl * 4) = v;
       }
     }
