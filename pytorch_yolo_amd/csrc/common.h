@@ -38,10 +38,12 @@ __device__ __forceinline__ float bf16_bits_to_f32(uint32_t hi16) { return __uint
 // (0,1 = x,y; 2,3 = w,h; 4 = objectness; 5.. = classes) at grid cell (gx, gy); anchor = anchor_px / stride for
 // this role.  Shared by the standalone decode kernel and the head-conv epilogue so that both give the same bits.
 __device__ __forceinline__ float yolo_decode_elem(float r, int k, int gx, int gy, float anchor, float stride, int nc) {
-  // one exponential and one division per element whatever the role (the roles differ per lane inside a wave)
+  // one exponential and one reciprocal per element whatever the role (the roles differ per lane inside a wave).  Round 3: the
+  // hardware forms (v_exp_f32 on r * log2(e), v_rcp_f32: about 2 ulp together, far inside the 2e-6 the decode is checked to) instead
+  // of expf() + an IEEE division, ~6 instead of ~25 VALU instructions per element of 68.5 M per 32 SPP-640 images
   const bool wh = (k & ~1) == 2;
-  const float e = expf(wh ? r : -r);
-  const float sg = 1.f / (1.f + e);                                   // sigmoid(r) where it is used
+  const float e = __expf(wh ? r : -r);
+  const float sg = __builtin_amdgcn_rcpf(1.f + e);                    // sigmoid(r) where it is used
   float v = sg;                                                       // :93
   if (k < 2) v = (sg + (float)(k == 0 ? gx : gy)) * stride;           // :91,:94
   if (wh) v = (e * anchor) * stride;                                  // :92,:94
