@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_t20v2_kernel(const ConvArgs a)
   };
 
   const int nch = d.cin / 32;
+  __builtin_assume(nch >= 1);                          // (launcher: cin % 32 == 0, cin > 0) - without it the loop guard makes the compiler zero the 200 accumulators twice
   bf16x8 wf[3][2], xf[XD];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -382,6 +383,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_t20_kernel(const ConvArgs a)
   };
 
   const int nch = d.cin / 32;
+  __builtin_assume(nch >= 1);                          // (launcher: cin % 32 == 0, cin > 0) - without it the loop guard makes the compiler zero the 200 accumulators twice
   wait_lds();                                          // (the table entries are this thread's own)
   static_for<AHEAD>([&](auto kc) {                     // planes 0 .. AHEAD - 1 of chunk 0
     constexpr int k = decltype(kc)::value;
