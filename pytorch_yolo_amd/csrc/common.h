@@ -36,14 +36,19 @@ __device__ __forceinline__ float bf16_bits_to_f32(uint32_t hi16) { return __uint
 
 // One element of the YOLOLayer decode (reference models/yolo_layer.py:90-96): raw head value r of role k
 // (0,1 = x,y; 2,3 = w,h; 4 = objectness; 5.. = classes) at grid cell (gx, gy); anchor = anchor_px / stride for
-// this role.  Shared by the standalone decode kernel and the head-conv epilogue so that both give the same bits.
+// this role.  One exponential and one reciprocal per element whatever the role (the roles differ per lane inside a wave).
+//   PRECISE = true : expf() + an IEEE division (each <= 1 ulp).  The standalone decode kernel (yolo_decode_fwd), i.e. the
+//                    decode of model.precision = "fp32" - the parity mode whose kept-index sets are compared with the reference's.
+//   PRECISE = false: v_exp_f32 on r * log2(e) and v_rcp_f32 (~6 instead of ~25 VALU instructions for each of the 68.5 M head
+//                    elements of 32 SPP-640 images): the head conv's epilogue (yolo_head_decode_fwd), i.e. the bf16 path.  The
+//                    product r * log2(e) is rounded once, so exp's relative error is about (1.5 + |r|) * 2^-24: <= 1e-6
+//                    for |r| <= 15 and 2e-6 at |r| = 30 (w / h = exp(r) * anchor; where the sigmoid is used the ABSOLUTE error stays
+//                    below 2^-23 for every r).  tests: test_decode_vs_oracle (PRECISE), test_fused_head_decode_wide_logits (fast).
+template <bool PRECISE>
 __device__ __forceinline__ float yolo_decode_elem(float r, int k, int gx, int gy, float anchor, float stride, int nc) {
-  // one exponential and one reciprocal per element whatever the role (the roles differ per lane inside a wave).  Round 3: the
-  // hardware forms (v_exp_f32 on r * log2(e), v_rcp_f32: about 2 ulp together, far inside the 2e-6 the decode is checked to) instead
-  // of expf() + an IEEE division, ~6 instead of ~25 VALU instructions per element of 68.5 M per 32 SPP-640 images
   const bool wh = (k & ~1) == 2;
-  const float e = __expf(wh ? r : -r);
-  const float sg = __builtin_amdgcn_rcpf(1.f + e);                    // sigmoid(r) where it is used
+  const float e = PRECISE ? expf(wh ? r : -r) : __expf(wh ? r : -r);
+  const float sg = PRECISE ? 1.f / (1.f + e) : __builtin_amdgcn_rcpf(1.f + e);   // sigmoid(r) where it is used
   float v = sg;                                                       // :93
   if (k < 2) v = (sg + (float)(k == 0 ? gx : gy)) * stride;           // :91,:94
   if (wh) v = (e * anchor) * stride;                                  // :92,:94

@@ -439,7 +439,7 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NP)) void conv_igemm_bf16
         for (int j = 0; j < CJ; ++j) {
           if (c_k[j] < 0) continue;
           const float r = srow[lane + 64 * j];
-          const float v = yolo_decode_elem(r, c_k[j], gx, gy, c_anchor[j], h.stride, h.no - 5);
+          const float v = yolo_decode_elem<false>(r, c_k[j], gx, gy, c_anchor[j], h.stride, h.no - 5);
           if (pimg) pimg[c_poff[j]] = r;
           iimg[c_ioff[j]] = v;
         }

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
     const int b = (int)(pix / cells), cell = (int)(pix - (long)b * cells);
     const int gy = cell / a.nx, gx = cell - gy * a.nx;
     const float r = raw[i];
-    const float v = yolo_decode_elem(r, k, gx, gy, anchor, a.stride, a.nc);
+    const float v = yolo_decode_elem<true>(r, k, gx, gy, anchor, a.stride, a.nc);
     const long plane_elem = (long)cell * no + k;
     if (a.p) a.p[((long)b * a.na + an) * cells * no + plane_elem] = r;
     a.io[((long)b * a.io_rows_total + a.io_row_offset + (long)an * cells) * no + plane_elem] = v;

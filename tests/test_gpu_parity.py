@@ -5,7 +5,10 @@ Tolerances (stated once, used below):
   * pools / SPP / pack: exact (max and rounding are order-free).
   * conv (bf16 in, fp32 accumulate): against an fp32 conv of the SAME bf16-rounded operands,
     |err| <= 2e-3 * sqrt(K)-scaled bound -> we use rtol 1e-2 on the bf16-rounded output (1 bf16 ulp = 2^-8).
-  * decode: fp32, rtol 2e-6 / atol 1e-5 vs torch (expf vs Sleef exp differ by <= 1 ulp).
+  * decode: fp32 vs torch.  Standalone kernel (yolo_decode_fwd: expf + IEEE division, the decode of precision = "fp32"):
+    rtol 2e-6 / atol 1e-5 for |logit| up to 30, <= 2 ulp on values straddling the NMS thresholds.  Head-conv epilogue (the bf16
+    path: v_exp_f32 on r * log2 e + v_rcp_f32): w / h relative error <= (3 + |r|) * 2^-23, sigmoid absolute error <= 2^-22
+    (test_fused_head_decode_wide_logits).
   * NMS: kept-index sets, conf, class_conf, class BIT-EXACT vs the oracle; merged boxes bit-exact vs the
     oracle (same sequential fp32 order) and within 2e-4 px of the reference golden.
   * whole model in bf16 vs the fp32 oracle: boxes within max(1.5 px, 2 %), scores within 2e-2 (4e-2 for YOLOv3, see there)
@@ -673,6 +676,76 @@ def test_decode_vs_oracle(nc, ny, nx, img):
     assert layer.stride == img / max(nx, ny)
     if nc == 1:
         assert torch.all(io[..., 5] == 1)
+
+
+def test_decode_wide_logits_and_threshold_straddlers():
+    """the decode beyond randn * 2.  (a) logits uniform in [-30, 30] (w / h up to e^30 anchors) hold the same
+    rtol 2e-6; (b) logits placed 0, +-1, +-2, +-8 fp32 steps around logit(t) for the thresholds an NMS call uses (0.001 ... 0.9):
+    the decoded sigmoid is within 2 ulp of torch's, so an objectness that the reference puts a few ulp on one side of a threshold
+    cannot land far on the other side (the kept-index comparison of the fp32 mode rests on this kernel)."""
+    from pytorch_yolo_amd.models.yolo_layer import YOLOLayer
+    from oracle.blocks import yolo_decode
+    nc, ny, nx, img = 80, 13, 13, 416
+    anchors = C.TINY_ANCHORS[1]
+    g = torch.Generator().manual_seed(77)
+    p_raw = (torch.rand(2, 3 * (5 + nc), ny, nx, generator=g) - 0.5) * 60.0
+    layer = YOLOLayer(anchors, nc, C.TINY_ANCHORS).eval()
+    io, p = layer(p_raw.to(DEV), img)
+    io_ref, p_ref = yolo_decode(p_raw, anchors, nc, img)
+    assert torch.equal(p.cpu(), p_ref)
+    torch.testing.assert_close(io.cpu(), io_ref, rtol=2e-6, atol=1e-5)
+    thr = torch.tensor([0.001, 0.01, 0.1, 0.25, 0.5, 0.75, 0.9], dtype=torch.float64)
+    base = torch.log(thr / (1 - thr)).float()
+    steps = torch.tensor([-8, -2, -1, 0, 1, 2, 8], dtype=torch.int32)
+    vals = (base.view(-1, 1).view(torch.int32) + steps.view(1, -1)).view(torch.float32).reshape(-1)     # neighbouring floats
+    p_raw = vals[torch.randint(0, vals.numel(), (2, 3 * (5 + nc), ny, nx), generator=g)]
+    io, _ = layer(p_raw.to(DEV), img)
+    io_ref, _ = yolo_decode(p_raw, anchors, nc, img)
+    sc, sc_ref = io.cpu()[..., 4:], io_ref[..., 4:]
+    ulps = ((sc.view(torch.int32) - sc_ref.view(torch.int32)).abs()).max().item()
+    print(f"[decode] sigmoid on threshold straddlers: max distance to torch {ulps} ulp")
+    assert ulps <= 2
+
+
+def test_fused_head_decode_wide_logits():
+    """The head conv's decode epilogue (hardware exp / reciprocal, common.h yolo_decode_elem<false>) on logits up to |r| ~ 30,
+    against the reference formulas evaluated in float64 ON ITS OWN raw logits p (so only the decode is measured): w / h relative
+    error <= (3 + |r|) * 2^-23, sigmoid / xy absolute error <= 2^-22 (* stride for xy)."""
+    from pytorch_yolo_amd import kernels as K
+    from pytorch_yolo_amd._lib import ACT_NONE, DT_F32
+    n, h, w, cin, nc = 2, 13, 13, 64, 80
+    na, no = 3, nc + 5
+    cout = na * no
+    anchors = [(10., 13.), (33., 23.), (59., 119.)]
+    stride = 32.0
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) * (6.0 / cin ** 0.5)           # logit std ~6 ...
+    bias = (torch.rand(cout, generator=g) - 0.5) * 30.0                           # ... around a bias in [-15, 15]
+    xin = _nhwc(x).to(torch.bfloat16).to(DEV).contiguous()
+    wp, bp, kpad, cout_pad = K.pack_conv_weight(wt, bias, cin)
+    d = K.conv_desc(n=n, h=h, w=w, cin=cin, in_c_total=cin, in_c_offset=0, cout=cout, out_c_total=K.roundup(cout, 8),
+                    out_c_offset=0, ksize=1, stride=1, act=ACT_NONE, kpad=kpad, cout_pad=cout_pad, out_dtype=DT_F32)
+    io = torch.empty((n, na * h * w, no), device=DEV)
+    p = torch.empty((n, na, h, w, no), device=DEV)
+    K.head_decode(xin, wp.to(DEV), bp.to(DEV), d, anchors, nc, stride, io, 0, p)
+    torch.cuda.synchronize()
+    r = p.cpu().double()
+    assert float(r.abs().max()) > 25.0, "the case does not reach wide logits"
+    got = io.cpu().double().view(n, na, h, w, no)
+    yv, xv = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+    grid = torch.stack((xv, yv), 2).double().view(1, 1, h, w, 2)
+    anc = (torch.tensor(anchors, dtype=torch.float32) / stride).double().view(1, na, 1, 1, 2)
+    xy = (torch.sigmoid(r[..., :2]) + grid) * stride
+    wh = torch.exp(r[..., 2:4]) * anc * stride
+    sg = torch.sigmoid(r[..., 4:])
+    assert float((got[..., :2] - xy).abs().max()) <= stride * 2.0 ** -20          # (sigmoid + cell index <= 13: half an ulp of the sum is 2^-21)
+    assert float((got[..., 4:] - sg).abs().max()) <= 2.0 ** -22
+    rel = (got[..., 2:4] - wh).abs() / wh
+    bound = (3.0 + r[..., 2:4].abs()) * 2.0 ** -23
+    print(f"[head decode] wide logits: |r| max {float(r.abs().max()):.1f}, w/h rel err max {float(rel.max()):.2e} "
+          f"(bound at that r {float(bound[rel == rel.max()].max()):.2e})")
+    assert bool((rel <= bound).all())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1561,6 +1634,146 @@ def test_headline_config_bs32_two_streams():
     assert min(n) > 0
 
 
+@pytest.mark.parametrize("cu_partition", [True, False])
+def test_benched_launch_list_bs32_whole_batch(cu_partition):
+    """The launch list ``bench.py`` times - YOLOv3-SPP 640x640, ONE 32-image list per pipeline
+    (``launch_detect(join=False, whole_batch=True)``), with ``cu_partition=True`` on CU-masked streams and tile rules sized for
+    128 CUs, and without it (what ``detect_stream()`` runs) - under the oracle, at full size
+    (the composition of reference utils/utils.py:374-378 on the configuration BASELINE.json quotes):
+      (a) the partitioned call really launches on ExternalStreams (hipExtStreamCreateWithCUMask), the plain one never creates them;
+      (b) image 0's ``io`` rows against the reference golden at the bounds of the bs = 1 test, images 13 / 31 against the fp32 oracle;
+      (c) the detections of all 32 images == the oracle NMS on that ``io``, bit for bit;
+      (d) raw head logits against the n = 16 / 256-CU lists that ``model(x)`` runs.  The two lists pick kernels with another K order
+          on two layers only (the 80 -> 40 and 40 -> 20 stride-2 convs: parity planes vs the gather form); launches 0 - 21 are
+          bit-equal, launch 22 differs by ONE bf16 ulp on 0.03 % of its outputs, and from there the share of differing values grows
+          launch by launch (0.2 %, 1 %, 2.5 %, ... 80 %: profiles/r04_list_diff_spp640.txt, tools/list_diff.py) - a single flipped
+          rounding re-draws the roundings downstream, so the two lists end as two realisations of the SAME bf16 rounding noise:
+          their mutual distance per head must stay below the distance the rounding model puts between one realisation and fp32
+          (test_bf16_path_within_its_rounding_budget: 3.6e-3 / 3.8e-3 / 6.4e-3; measured 2.7e-3 / 3.1e-3 / 5.6e-3).  "Within 2 bf16
+          ulp on the head inputs" (VERDICT r3) is not reachable by any two lists that differ anywhere: see the growth table;
+      (e) four successive calls (both pipelines, twice each) give bit-identical ``io`` and detections."""
+    from oracle import models as om
+    from oracle import nms as onms
+    from pytorch_yolo_amd.utils.utils import nms_capacity
+    case = C.FULL_CASES["spp_640"]
+    model, sd, _ = build_case(case)
+    g = load_golden("full_spp_640")
+    x = _seeded_batch(32, 640)
+    model = model.to(DEV)
+    xd = x.to(DEV)
+    model.n_streams = 2
+    plan = model.plan_for(xd)
+    assert type(plan).__name__ == "StreamedPlan"
+    cap = nms_capacity(plan.rows_total, model.n_class)
+    runs = []
+    with torch.no_grad():
+        io16, p16 = model(xd)                                   # two 16-image lists, ordinary streams, 256-CU rules
+        torch.cuda.synchronize()
+        for call in range(4):
+            io, ps = plan.new_outputs(want_p=(call == 0))       # bench.py runs without p; call 0 keeps it for (d)
+            out = (torch.empty((32, cap, 7), device=DEV), torch.empty((32, cap), dtype=torch.int32, device=DEV),
+                   torch.empty((32,), dtype=torch.int32, device=DEV))
+            plan.launch_detect(xd, io, ps, out, C.NMS_FULL["conf_thres"], C.NMS_FULL["nms_thres"], join=False, whole_batch=True,
+                               cu_partition=cu_partition)
+            runs.append((io, ps, out))
+        torch.cuda.synchronize()
+    # (a)
+    assert plan._full is not None and len(plan._full) == 2 and plan._full[0].rec.input.n == 32
+    if cu_partition:
+        assert plan._full_streams is not None and all(type(st).__name__ == "ExternalStream" for st in plan._full_streams), \
+            "cu_partition=True did not launch on CU-masked streams"
+    else:
+        assert plan._full_streams is None
+    # (e)
+    io0, ps0, out0 = runs[0]
+    n0 = out0[2].cpu()
+    for io, _, out in runs[1:]:
+        assert torch.equal(io, io0), "whole-batch lists are not run-to-run / pipeline-to-pipeline identical"
+        assert torch.equal(out[2].cpu(), n0)
+        for b in range(32):
+            assert torch.equal(out[0][b, :n0[b]], out0[0][b, :n0[b]])
+    # (b)
+    io_c = io0.cpu()
+    _assert_model_close(io_c[:1][:, g["rows"]], torch.from_numpy(g["io_rows"]), "benched list, image 0 / golden rows", score_max=0.18, score_rms=1e-2)
+    for i in (13, 31):
+        io_ref, _ = om.spp_forward(sd, x[i:i + 1], C.SPP_ANCHORS, 80)
+        _assert_model_close(io_c[i:i + 1], io_ref, f"benched list, image {i} vs fp32 oracle", score_max=0.225, score_rms=1e-2)
+    # (c)
+    odets, _ = onms.non_max_suppression(io_c.numpy().copy(), **C.NMS_FULL)
+    dets = out0[0].cpu().numpy()
+    for b in range(32):
+        assert (odets[b] is None) == (int(n0[b]) == 0)
+        if odets[b] is not None:
+            assert np.array_equal(dets[b, :int(n0[b])], odets[b]), f"image {b}: detections differ from the oracle NMS"
+    assert int(n0.min()) > 0
+    # (d)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    for k, budget in enumerate((3.6e-3, 3.8e-3, 6.4e-3)):
+        r = rel(ps0[k], p16[k])
+        print(f"[benched list, cu_partition={cu_partition}] head {k} raw logits vs the 16-image / 256-CU lists: rel rms {r:.2e} (bf16 budget {budget:.1e})")
+        assert r <= budget, f"head {k}: the two lists are further apart than one of them may be from fp32"
+    d_sc = float((io0[..., 4:] - io16[..., 4:]).abs().max())
+    print(f"[benched list, cu_partition={cu_partition}] scores vs the 16-image lists: max abs diff {d_sc:.4f}; "
+          f"detections per image: min {int(n0.min())}, mean {float(n0.float().mean()):.1f}")
+    assert d_sc <= 0.25
+
+
+def test_benched_list_diverges_only_where_the_summation_order_does():
+    """Launch-by-launch companion of (d) above (tools/list_diff.py as a test): the 16-image / 256-CU list and the 32-image /
+    128-CU list on the same images, one launch at a time.  While both lists have picked the same kernel family for every launch so
+    far, outputs are BIT-EQUAL (batch size, grid size and tile shape do not change a value: K is walked in the same order); the
+    first launch where the families differ (gather form vs parity planes on the 80 -> 40 stride-2 conv) may differ by one bf16
+    ulp on a small share of its outputs - nothing else."""
+    import ctypes as CT
+    from pytorch_yolo_amd import engine, kernels as K
+    from pytorch_yolo_amd._lib import OP_CONV, OP_HEAD_DECODE, YoloOp
+    case = C.FULL_CASES["spp_640"]
+    model, sd, _ = build_case(case)
+    model = model.to(DEV)
+    x = _seeded_batch(32, 640).to(DEV)
+
+    def make(bs):
+        rec = engine.Recorder(bs, 3, 640, 640)
+        model._trace(rec, rec.input)
+        return engine.Plan(rec, torch.device(DEV), 80, 640)
+    pa, pb = make(16), make(32)
+    pa.feed(x[:16].contiguous()), pb.feed(x)
+    pa._bind_outputs(*pa.new_outputs()), pb._bind_outputs(*pb.new_outputs())
+    fam = lambda s_: s_.split("<")[0]
+    diverged, checked_equal = False, 0
+    for i in range(pa.n_ops):
+        if pa.op_array[i].kind == OP_HEAD_DECODE:
+            break
+        names = []
+        for plan, cus in ((pa, 256), (pb, 128)):
+            old = K.set_launch_cus(cus)
+            try:
+                op = plan.op_array[i]
+                names.append(fam(K.conv2d_pick(op.conv, bool(op.residual), bool(op.y_aux))) if op.kind == OP_CONV else f"kind {op.kind}")
+                K.run_ops(CT.cast(CT.byref(plan.op_array, i * CT.sizeof(YoloOp)), CT.POINTER(YoloOp)), 1)
+            finally:
+                K.set_launch_cus(old)
+        outs = []
+        for plan in (pa, pb):
+            nd = plan.op_nodes[i]
+            sy = (nd.attrs.get("up_into") or nd.attrs.get("pool_into") or nd.outs[0]) if nd.kind == "conv" else nd.outs[0]
+            outs.append(sy.buf.tensor[:16, ..., sy.c_offset:sy.c_offset + sy.c])
+        a, b = outs
+        if names[0] == names[1] and not diverged:
+            assert torch.equal(a, b), f"launch {i} ({names[0]}): same kernel family, same inputs, different outputs"
+            checked_equal += 1
+            continue
+        if not diverged:
+            diverged = True
+            d = (a.float() - b.float()).abs()
+            share = float((d != 0).float().mean())
+            ulp = float((d / a.float().abs().clamp_min(2.0 ** -120)).max())
+            print(f"[list diff] launches 0..{i - 1} bit-equal; launch {i} ({names[0]} vs {names[1]}): {100 * share:.3f} % of the outputs differ, by at most {ulp:.4f} relative")
+            assert share <= 2e-3 and ulp <= 2.0 ** -7, "the first diverging launch differs by more than single bf16 roundings"
+            break
+    assert diverged and checked_equal >= 20
+
+
 def test_secondary_configs_at_bench_batch_sizes():
     """YOLOv3-tiny 416x416 bs=32 (two streams of 16) and YOLOv3-tiny/MobileNetV2 416x416 bs=64 (two streams of 32): sampled
     images against the fp32 oracle with the small-model bounds."""
@@ -1589,6 +1802,84 @@ def test_secondary_configs_at_bench_batch_sizes():
         for i in (0, 40, 63):
             io_ref, _ = om.tiny_mobile_forward(sdm, xm[i:i + 1], om.TINY_ANCHORS, 80)
             _assert_model_close(io.cpu()[i:i + 1], io_ref, f"mobile_416x64 image {i}", score_max=3e-2, score_rms=4e-3)
+
+
+# ------------------------------------------------------------------------------------------------
+# memory-safety audit of the launch lists
+def _guarded(shape, dtype, rz=65536, fill=0x7F):
+    """A tensor in the middle of a larger allocation whose margins hold ``fill``; returns (tensor, raw bytes, rz)."""
+    numel = int(np.prod(shape))
+    nbytes = numel * torch.empty((), dtype=dtype).element_size()
+    raw = torch.full((nbytes + 2 * rz,), fill, dtype=torch.uint8, device=DEV)
+    return raw[rz:rz + nbytes].view(dtype).view(shape), raw, rz
+
+
+def _margins_intact(raw, rz, fill=0x7F):
+    return bool((raw[:rz] == fill).all()) and bool((raw[-rz:] == fill).all())
+
+
+@pytest.mark.parametrize("name", ["tiny_416x32", "mobile_416x64", "spp_640x32", "tiny_416x32_fp32"])
+def test_launch_lists_stay_inside_their_buffers(name, monkeypatch):
+    """Dynamic bounds audit of the BASELINE launch lists at the bench shapes (the tiny-416 x 32 list is the one whose HIP-graph
+    replay ended in a GPU memory access fault in round 3).  Every activation buffer, packed weight and bias of the plan
+    (engine.Plan, YOLO_REDZONE), the input batch, io, the NMS outputs and the NMS workspace sit inside larger allocations whose
+    64 KB margins are poisoned with 0x7f bytes (3.4e38 as bf16 / f32).  After forward + decode + NMS:
+      * writes: every margin still holds the poison;
+      * reads: io and the detections are bit-equal to those of a plain plan - a kernel that picked up margin bytes (a max pool
+        window, a halo pixel, a weight row past the matrix) would carry 3.4e38 / inf / NaN into them.
+    The static side of the audit (what every launch may touch by the C ABI's contract against the planner's allocations) is
+    tests/test_host_cpu.py::test_every_launch_stays_inside_the_plans_allocations."""
+    from pytorch_yolo_amd import YOLOv3TinyMobile, engine, kernels as K
+    from pytorch_yolo_amd.utils.synthetic import synth_state_dict
+    from pytorch_yolo_amd.utils.utils import MAX_PER_CLASS, MIN_WH, nms_capacity
+    fp32 = name.endswith("_fp32")
+    if name.startswith("tiny"):
+        model, sd, _ = build_case(C.FULL_CASES["tiny_416"])
+        bs, hw = 32, 416
+    elif name.startswith("mobile"):
+        model = YOLOv3TinyMobile(n_class=80).eval()
+        model.load_state_dict(synth_state_dict(model.state_dict(), 1234, n_class=80))
+        bs, hw = 64, 416
+    else:
+        model, sd, _ = build_case(C.FULL_CASES["spp_640"])
+        bs, hw = 32, 640
+    model = model.to(DEV)
+    x_plain = _seeded_batch(bs, hw).to(DEV)
+
+    def run(guard):
+        if guard:
+            monkeypatch.setenv("YOLO_REDZONE", "65536")
+        else:
+            monkeypatch.delenv("YOLO_REDZONE", raising=False)
+        rec = engine.Recorder(bs, 3, hw, hw)
+        model._trace(rec, rec.input)
+        plan = engine.Plan(rec, torch.device(DEV), model.n_class, hw, "fp32" if fp32 else "bf16")
+        no, cap = model.n_class + 5, nms_capacity(plan.rows_total, model.n_class)
+        shapes = [((bs, 3, hw, hw), torch.float32), ((bs, plan.rows_total, no), torch.float32), ((bs, cap, 7), torch.float32),
+                  ((bs, cap), torch.int32), ((bs,), torch.int32), ((K.nms_workspace_bytes(bs, plan.rows_total, model.n_class),), torch.uint8)]
+        shapes += [((bs, hd["na"], hd["sym"].h, hd["sym"].w, no), torch.float32) for hd in plan.heads]
+        ts = [_guarded(sh, dt) if guard else (torch.empty(sh, dtype=dt, device=DEV), None, 0) for sh, dt in shapes]
+        x, io, dets, idx, cnt, ws = (t[0] for t in ts[:6])
+        ps = tuple(t[0] for t in ts[6:])
+        x.copy_(x_plain)
+        with torch.no_grad():
+            plan._launch(x, io, ps)
+            K.nms_merge(io, C.NMS_FULL["conf_thres"], C.NMS_FULL["nms_thres"], dets, idx, cnt, ws, min_wh=MIN_WH, max_per_class=MAX_PER_CLASS)
+        torch.cuda.synchronize()
+        return plan, ts, io, ps, dets, cnt
+
+    plan_g, ts_g, io_g, ps_g, dets_g, cnt_g = run(True)
+    assert len(plan_g._redzones) >= plan_g.n_ops, "the plan's buffers were not guarded"
+    assert plan_g.redzone_report() == [], f"a launch wrote outside a plan buffer: {plan_g.redzone_report()}"
+    for i, (_, raw, rz) in enumerate(ts_g):
+        assert _margins_intact(raw, rz), f"a launch wrote outside call buffer {i} (x, io, dets, idx, count, nms workspace, p...)"
+    plan_p, _, io_p, ps_p, dets_p, cnt_p = run(False)
+    assert torch.equal(io_g, io_p), "io differs between the guarded and the plain plan: a kernel reads outside its buffers"
+    assert all(torch.equal(a, b) for a, b in zip(ps_g, ps_p))
+    assert torch.equal(cnt_g, cnt_p) and int(cnt_p.sum()) > 0
+    for b in range(bs):
+        assert torch.equal(dets_g[b, :cnt_p[b]], dets_p[b, :cnt_p[b]])
+    assert bool(torch.isfinite(io_p).all())
 
 
 # ------------------------------------------------------------------------------------------------

@@ -105,7 +105,7 @@ def test_fold_bn_matches_oracle():
 def _dry_plan(model, hw, bs=1):
     rec = engine.Recorder(bs, 3, hw, hw)
     model._trace(rec, rec.input)
-    return engine.Plan(rec, torch.device("cpu"), model.n_class, hw)
+    return engine.Plan(rec, torch.device("cpu"), model.n_class, hw, model.precision)
 
 
 def _ops(plan):
@@ -180,6 +180,101 @@ def test_planner_tiny_and_mobile():
     assert plan.fused_input and first.kind == OP_CONV1_NCHW and (first.conv.stride, first.conv.cout, first.conv.ho) == (2, 32, 208)
     assert kinds.count(OP_DWCONV) == 10 and kinds.count(OP_CONV) == 24 and kinds.count(OP_HEAD_DECODE) == 2
     assert sum(1 for o in _ops(plan) if o.kind == OP_CONV and o.residual) == 7           # MobileNetV2 identity shortcuts of the wide blocks
+
+
+@pytest.mark.parametrize("family,bs,hw,precision", [("tiny", 32, 416, "bf16"), ("tiny", 4, 416, "fp32"), ("mobile", 16, 416, "bf16"),
+                                                     ("spp", 8, 640, "bf16"), ("spp", 1, 640, "fp32")])
+def test_every_launch_stays_inside_the_plans_allocations(family, bs, hw, precision):
+    """Static memory audit of the BASELINE launch lists.  For every launch of a plan built on the CPU, the byte
+    range each pointer may be dereferenced over BY THE C ABI'S CONTRACT (include/yolo_hip.h: a view is [n, h, w, c_total] elements
+    from its base, a packed weight matrix is cout_pad x kpad, a bias is cout_pad floats) must lie inside ONE allocation the plan
+    owns (an activation buffer or a packed weight it keeps alive), reads and writes alike; buffers that share storage
+    (engine.Plan._alloc) must have identical extents.  Catches planner errors: a view wider than its buffer, a shared buffer of
+    another size, a weight packed for fewer input channels than the conv reads, a pooled / upsampled output sized for the wrong map.
+    (The kernels' own indexing is audited dynamically on the GPU: test_launch_lists_stay_inside_their_buffers.)"""
+    from pytorch_yolo_amd._lib import OP_CONV_F32, OP_MAXPOOL_F32
+    model = {"tiny": YOLOv3Tiny, "mobile": YOLOv3TinyMobile, "spp": lambda: YOLOv3SPP(anchors=C.SPP_ANCHORS)}[family]().eval()
+    model.precision = precision
+    plan = _dry_plan(model, hw, bs=bs)
+    allocs = {}
+    for b in plan._bufs:
+        t = b.tensor
+        size = t.numel() * t.element_size()
+        assert allocs.setdefault(t.data_ptr(), size) == size, "two buffers share storage but not their size"
+    for t in plan._keep:
+        allocs[t.data_ptr()] = t.numel() * t.element_size()
+    starts = sorted(allocs)
+
+    def inside(ptr, nbytes, what):
+        import bisect
+        assert nbytes > 0, what
+        i = bisect.bisect_right(starts, ptr) - 1
+        assert i >= 0 and ptr + nbytes <= starts[i] + allocs[starts[i]], \
+            f"{what}: [{ptr:#x}, +{nbytes}) is not inside one allocation of the plan"
+
+    f32 = precision == "fp32"
+    es = 4 if f32 else 2
+    checked = 0
+    for i, op in enumerate(_ops(plan)):
+        d, tag = op.conv, f"op {i} kind {op.kind}"
+        m_in, m_out = d.n * d.h * d.w, d.n * d.ho * d.wo
+        if op.kind in (OP_CONV, OP_CONV_F32, OP_CONV_POOL, OP_CONV1_NCHW, OP_CONV1_POOL, OP_HEAD_DECODE, OP_RESUNIT, OP_STEM):
+            first = op.kind in (OP_CONV1_NCHW, OP_CONV1_POOL, OP_STEM)
+            if first:
+                assert not op.x                                      # the caller's NCHW batch: bound per call (Plan.feed checks its shape)
+            else:
+                inside(op.x, m_in * d.in_c_total * es, tag + " x")
+                assert d.in_c_offset + d.cin <= d.in_c_total
+            inside(op.w, d.cout_pad * d.kpad * es, tag + " w")
+            inside(op.bias, d.cout_pad * 4, tag + " bias")
+            # a conv's k index runs to k*k*cin of the view it reads (the stem's second conv: 9 * 32)
+            assert d.kpad >= d.ksize * d.ksize * (32 if op.kind == OP_STEM else d.cin) and d.cout_pad >= d.cout, tag
+            if op.kind == OP_HEAD_DECODE:
+                assert not op.y and not op.y_aux                     # io / p of the call: bound per call (Plan._bind_outputs checks io)
+            else:
+                scale = 4 if d.upsample2x else 1
+                if op.kind in (OP_CONV_POOL, OP_CONV1_POOL):
+                    m_y = d.n * (d.ho // 2) * (d.wo // 2)
+                else:
+                    m_y = m_out * scale
+                inside(op.y, m_y * d.out_c_total * (4 if (d.out_dtype or f32) else 2), tag + " y")
+                assert d.out_c_offset + d.cout <= d.out_c_total + (7 if d.out_dtype else 0)
+            if op.residual:
+                inside(op.residual, m_out * d.res_c_total * es, tag + " residual")
+                assert d.res_c_offset + d.cout <= d.res_c_total
+            if op.y_aux and op.kind != OP_HEAD_DECODE:
+                inside(op.y_aux, m_out * d.aux_c_total * es, tag + " pre-add copy")
+                assert d.aux_c_offset + d.cout <= d.aux_c_total
+            if op.kind == OP_RESUNIT:
+                inside(op.w_pre, op.cout_pad_pre * op.kpad_pre * 2, tag + " w1")
+                inside(op.bias_pre, op.cout_pad_pre * 4, tag + " b1")
+                assert op.kpad_pre >= d.cout and op.cout_pad_pre >= d.cin
+            if op.kind == OP_STEM:
+                inside(op.w_pre, 128 * op.kpad_pre * 2, tag + " w1")
+                inside(op.bias_pre, 128 * 4, tag + " b1")
+        elif op.kind in (OP_MAXPOOL, OP_MAXPOOL_F32, OP_DWCONV):
+            inside(op.x, m_in * d.in_c_total * es, tag + " x")
+            inside(op.y, m_out * d.out_c_total * es, tag + " y")
+            assert d.in_c_offset + d.cin <= d.in_c_total and d.out_c_offset + d.cin <= d.out_c_total
+            if op.kind == OP_DWCONV:
+                inside(op.w, 9 * d.cin * 4, tag + " w")
+                inside(op.bias, d.cin * 4, tag + " bias")
+        elif op.kind == OP_SPP:
+            inside(op.y, m_in * 4 * d.cin * 2, tag + " concat buffer")
+        elif op.kind == OP_MBCONV:
+            inside(op.x, m_in * d.in_c_total * 2, tag + " x")
+            inside(op.y, m_out * d.out_c_total * 2, tag + " y")
+            ce = K.roundup(op.kpad_pre, 32)
+            inside(op.w, K.roundup(d.cout, 16) * (_lib.load().yolo_mbconv_dstride(ce) // 2) * 2, tag + " w proj")
+            inside(op.w_dw, 9 * ce * 4, tag + " w dw")
+            inside(op.bias_dw, ce * 4, tag + " b dw")
+            if op.w_pre:
+                inside(op.w_pre, ce * 48 * 2, tag + " w expand")
+                inside(op.bias_pre, ce * 4, tag + " b expand")
+        else:
+            raise AssertionError(f"{tag}: not covered by the audit")
+        checked += 1
+    assert checked == plan.n_ops
 
 
 def test_planner_squeezenet_variant():
