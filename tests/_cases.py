@@ -101,6 +101,123 @@ def calibrate_separable_heads(bn_weight, bn_bias, p_raw, n_class: int = 80, per_
     return out_w, out_b
 
 
+# ---- detection-level fixtures selected by a RULE on the fp32 reference alone (round 4) --------------------------
+# The round-3 case above was picked by its outcome (the one seed of 39 whose two CPU runs paired 1.00) and placed its objectness cut
+# in whatever gap lay near the 5th cell (0.005 - 0.012 wide: narrower than twice the bf16 drift of 0.007).  These cases are chosen
+# blind: a patch-image seed qualifies when the REFERENCE's own fp32 outputs satisfy ``rule_verdict`` below (tests/diag/rule_search.py
+# scans seeds upward; the first qualifying ones are committed, whatever a bf16 run makes of them).
+# Why the objectness gain stays large (800; VERDICT r3 proposed 10 - 30): SPP's heads are ConvBlocks - the BN output passes
+# LeakyReLU(0.1) before the sigmoid (reference models/yolov3_spp.py:86,99,111), which divides every NEGATIVE logit by 10.  A cell
+# below the cut needs a BN output <= -22 to score obj <= 0.1, a cell above it >= +2.2 for obj >= 0.9; with both edges of the gap
+# at least 4 drifts (0.028) from a centred cut that is a gain >= 786.  What makes the cases robust is therefore not a small gain
+# but the WIDTH of the gap the cut sits in: >= 8 drifts by construction (anchors without such a gap are switched off), so a drift of
+# 0.007 moves a firing cell's logit by 5.6 of >= 22 (saturated: obj = 1.000 either way) and a silent cell's by 0.56 of <= -2.2
+# after the LeakyReLU (obj <= 0.16): no cell can cross, and conf of a detection is its class score, whose gain is <= 3.
+RULE = dict(weight_seed=1234, n_patches=120, max_rank=24, gamma_obj=800.0, cls_gain=3.0, conf_thres=0.5, nms_thres=0.5,
+            drift=0.007, min_gap_drifts=8.0, conf_band=0.05, iou_band=0.1, min_detections=8, class_margin=2.0)
+
+
+RULE_SEEDS = (1, 3, 5, 6)              # the first four patch-image seeds that qualify, scanning upward from 1 (tests/diag/rule_search.py)
+
+
+def calibrate_rule_heads(bn_weight, bn_bias, p_raw, rule, n_class: int = 80):
+    """Head BN (weight, bias) arrays for the rule cases, from the REFERENCE's raw head tensors ``p_raw[k]`` [3, ny, nx, 5 + nc] of one
+    image (LeakyReLU(0.1) outputs of that BN, reference models/yolov3_spp.py:86,99,111).  Per anchor: the objectness channel becomes
+    sigmoid(gamma (z - z0)) of the normalised conv output z with z0 in the middle of the DEEPEST gap of at least ``min_gap_drifts`` x ``drift`` between neighbours
+    among its ``max_rank`` + 1 largest cells; an anchor without such a gap than ``min_gap_drifts`` x ``drift`` is switched off
+    (objectness logit -30 everywhere) - so every cut of the case lies in a gap that the bf16 drift cannot close (rule R1 holds by
+    construction).  One live class channel per anchor (see below).  Returns (weights, biases, [gap or None per anchor])."""
+    no = 5 + n_class
+    out_w, out_b, gaps = [], [], []
+    for g, b, raw in zip(bn_weight, bn_bias, p_raw):
+        g, b = np.asarray(g, np.float64).copy(), np.asarray(b, np.float64).copy()
+        raw = np.asarray(raw, np.float64)
+        raw = np.where(raw < 0, raw * 10.0, raw)                    # undo the LeakyReLU: the BN outputs
+        for a in range(raw.shape[0]):
+            ch = a * no + 4
+            z = ((raw[a, :, :, 4] - b[ch]) / g[ch]).ravel()
+            order = np.argsort(-z, kind="stable")
+            zs = z[order]
+            wide = [i for i in range(1, rule["max_rank"] + 1) if zs[i - 1] - zs[i] >= rule["min_gap_drifts"] * rule["drift"]]
+            r = wide[-1] if wide else 1                             # the DEEPEST wide gap: as many firing cells as the rule allows
+            gap = zs[r - 1] - zs[r]
+            if not wide:
+                g[ch], b[ch] = 0.0, -30.0                           # anchor off
+                gaps.append(None)
+                continue
+            gaps.append(float(gap))
+            g[ch], b[ch] = rule["gamma_obj"], -rule["gamma_obj"] * 0.5 * (zs[r - 1] + zs[r])
+            # classes: ONE live class channel per anchor - the best class of its strongest cell -, scaled so that the firing cells score
+            # between logit 2.5 x gain and 8 on it; every other class channel is switched off (logit -30 -> -3 behind the LeakyReLU:
+            # 0.047), so the argmax over classes leads its runner-up by > 3 logits at every firing cell (rule R5 by construction)
+            cls = raw[a, :, :, 5:].reshape(-1, n_class)[order[:r]]
+            c_live = int(cls[0].argmax())
+            t = cls[:, c_live].min() - 2.5
+            gain = min(rule["cls_gain"], (8.0 - 0.37 * len(out_w) - 0.11 * a) / (cls[:, c_live].max() - t))
+            for c in range(n_class):
+                cch = a * no + 5 + c
+                if c == c_live:
+                    g[cch], b[cch] = g[cch] * gain, (b[cch] - t) * gain
+                else:
+                    g[cch], b[cch] = 0.0, -30.0
+        out_w.append(g.astype(np.float32))
+        out_b.append(b.astype(np.float32))
+    return out_w, out_b, gaps
+
+
+def rule_state_dict(sd, p_raw, rule):
+    """(state_dict with the calibrated head BN, gaps).  ``sd`` values are torch tensors; ``p_raw[k]`` = raw head k of ONE image."""
+    import torch
+    wk = [h + ".sequence.batch_norm.weight" for h in SEPARABLE_HEADS]
+    bk = [h + ".sequence.batch_norm.bias" for h in SEPARABLE_HEADS]
+    new_w, new_b, gaps = calibrate_rule_heads([sd[k].numpy() for k in wk], [sd[k].numpy() for k in bk], p_raw, rule)
+    out = dict(sd)
+    for k_w, k_b, w_, b_ in zip(wk, bk, new_w, new_b):
+        out[k_w], out[k_b] = torch.from_numpy(w_), torch.from_numpy(b_)
+    return out, gaps
+
+
+def rule_verdict(io0: np.ndarray, gaps, rule):
+    """(qualifies, reason) for ONE image's decoded fp32 reference rows ``io0`` [rows, 5 + nc] and the cut gaps: R1 - R4 of
+    tests/diag/rule_search.py.  Looks at nothing but the reference's fp32 outputs."""
+    live = [v for v in gaps if v is not None]
+    if not live or min(live) < rule["min_gap_drifts"] * rule["drift"]:
+        return False, "R1: no anchor with a wide enough cut gap"
+    cls = io0[:, 5:].max(1)
+    arg = io0[:, 5:].argmax(1)
+    conf = io0[:, 4] * cls
+    valid = (io0[:, 2] > 2.0) & (io0[:, 3] > 2.0)
+    near = valid & (np.abs(conf - rule["conf_thres"]) <= rule["conf_band"])
+    if near.any():
+        return False, f"R2: {int(near.sum())} rows with conf within {rule['conf_band']} of the threshold"
+    cand = np.nonzero(valid & (conf > rule["conf_thres"]))[0]
+    if len(cand) < rule["min_detections"]:
+        return False, f"R4: {len(cand)} candidates"
+    if len(np.unique(conf[cand])) != len(cand):
+        u, n = np.unique(conf[cand], return_counts=True)
+        return False, f"R4: conf ties ({len(cand)} candidates; tied values {u[n > 1][:4]})"
+    # R5 (added after the first GPU run of the R1 - R4 cases: seed 1 kept 8 of 9 detections within IoU 0.96 / |dconf| 0.006 and
+    # returned the ninth - best class logit 1.43 - under ANOTHER class): the argmax over classes must survive the stated per-logit
+    # bound of the bf16 mode (raw head logits within 1.0 of the reference, test_bf16_path_within_its_rounding_budget), i.e. the
+    # best class leads the runner-up by more than two such bounds
+    pc = np.sort(io0[cand, 5:].astype(np.float64), axis=1)
+    lg = np.log(pc[:, -2:] / (1.0 - pc[:, -2:]))
+    margin = lg[:, 1] - lg[:, 0]
+    if margin.min() < rule["class_margin"]:
+        return False, f"R5: best class leads the runner-up by {margin.min():.2f} logits at a candidate (< {rule['class_margin']})"
+    xy, wh = io0[cand, :2].astype(np.float64), io0[cand, 2:4].astype(np.float64)
+    x1, y1, x2, y2 = xy[:, 0] - wh[:, 0] / 2, xy[:, 1] - wh[:, 1] / 2, xy[:, 0] + wh[:, 0] / 2, xy[:, 1] + wh[:, 1] / 2
+    iw = np.clip(np.minimum(x2[:, None], x2[None]) - np.maximum(x1[:, None], x1[None]), 0, None)
+    ih = np.clip(np.minimum(y2[:, None], y2[None]) - np.maximum(y1[:, None], y1[None]), 0, None)
+    area = (x2 - x1) * (y2 - y1)
+    iou = iw * ih / (area[:, None] + area[None] - iw * ih + 1e-16)
+    same = (arg[cand][:, None] == arg[cand][None]) & ~np.eye(len(cand), dtype=bool)
+    band = same & (np.abs(iou - rule["nms_thres"]) <= rule["iou_band"])
+    if band.any():
+        return False, f"R3: {int(band.sum()) // 2} same-class candidate pairs with IoU within {rule['iou_band']} of the NMS threshold"
+    return True, f"{len(cand)} candidates from {len(live)} anchors, narrowest cut gap {min(live):.4f}, conf range [{conf[cand].min():.3f}, {conf[cand].max():.3f}]"
+
+
 def sample_rows(n_rows: int, seed: int = 7) -> np.ndarray:
     rng = np.random.default_rng(seed)
     return np.sort(rng.choice(n_rows, size=min(FULL_SAMPLE_ROWS, n_rows), replace=False))

@@ -194,6 +194,32 @@ def _separable_and_nms(ref, C, save, synth_images, synth_state_dict, only):
         save("full_spp_640_separable", **arrs)
         print("separable: detections", int(arrs["nms_count_0"]), "candidates", int(arrs["n_candidates"]), "between 0.4 and 0.6:", int(arrs["n_between_04_06"]),
               "min conf", float(arrs["nms_dets_0"][:, 4].min()))
+    # ---- full-size SPP-640 cases chosen by a rule on the reference's fp32 outputs alone (tests/_cases.py, RULE / RULE_SEEDS) ----
+    if only in (None, "rule"):
+        rule = C.RULE
+        model = ref["spp"](n_class=80, kernels_divider=1, anchors=C.SPP_ANCHORS).eval()
+        sd0 = synth_state_dict(model.state_dict(), rule["weight_seed"], n_class=80)
+        for seed in C.RULE_SEEDS:
+            model.load_state_dict(sd0)
+            x = torch.from_numpy(C.patch_image(seed, rule["n_patches"]))
+            with torch.no_grad():
+                _, p = model(x)
+            sd, gaps = C.rule_state_dict(sd0, [t[0].numpy() for t in p], rule)
+            model.load_state_dict(sd)
+            with torch.no_grad():
+                io, p = model(x)
+            io_np = io.numpy()
+            ok, why = C.rule_verdict(io_np[0], gaps, rule)
+            assert ok, f"rule case seed {seed} does not satisfy the rule on the reference's outputs: {why}"
+            rows = C.sample_rows(io_np.shape[1])
+            arrs = {"rows": rows, "io_rows": io_np[:, rows], "io_colsum": io_np.astype(np.float64).sum(1), "io_shape": np.asarray(io_np.shape),
+                    "cut_gaps": np.asarray([-1.0 if g is None else g for g in gaps])}
+            for k, h in enumerate(C.SEPARABLE_HEADS):
+                arrs[f"head_bn_weight_{k}"] = sd[h + ".sequence.batch_norm.weight"].numpy()
+                arrs[f"head_bn_bias_{k}"] = sd[h + ".sequence.batch_norm.bias"].numpy()
+            arrs.update({"nms_" + k: v for k, v in run_ref_nms(ref, io_np, rule["conf_thres"], rule["nms_thres"]).items() if not k.startswith("col4")})
+            save(f"full_spp_640_rule_{seed}", **arrs)
+            print(f"rule case {seed}: {why}; detections {int(arrs['nms_count_0'])}")
     if only is not None:
         return
 

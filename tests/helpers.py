@@ -47,6 +47,20 @@ def build_separable_case():
     return model, sd, torch.from_numpy(C.patch_image(sep["image_seed"], sep["n_patches"])), g
 
 
+def build_rule_case(seed: int):
+    """(product YOLOv3-SPP in eval mode, state_dict, x, golden) of one rule-selected case (tests/_cases.py::RULE, RULE_SEEDS): seeded
+    weights with the head BN arrays the golden stores (calibrated by make_golden.py from the reference's own raw head outputs)."""
+    rule = C.RULE
+    g = load_golden(f"full_spp_640_rule_{seed}")
+    model = YOLOv3SPP(n_class=80, kernels_divider=1, anchors=C.SPP_ANCHORS).eval()
+    sd = synth_state_dict(model.state_dict(), rule["weight_seed"], n_class=80)
+    for k, h in enumerate(C.SEPARABLE_HEADS):
+        sd[h + ".sequence.batch_norm.weight"] = torch.from_numpy(g[f"head_bn_weight_{k}"].copy())
+        sd[h + ".sequence.batch_norm.bias"] = torch.from_numpy(g[f"head_bn_bias_{k}"].copy())
+    model.load_state_dict(sd)
+    return model, sd, torch.from_numpy(C.patch_image(seed, rule["n_patches"])), g
+
+
 def box_iou(a, b):
     iw = max(0.0, min(a[2], b[2]) - max(a[0], b[0]))
     ih = max(0.0, min(a[3], b[3]) - max(a[1], b[1]))

@@ -22,7 +22,7 @@ import torch
 import torch.nn.functional as F
 
 import _cases as C
-from helpers import build_case, build_separable_case, load_golden, oracle_forward, strict_share
+from helpers import build_case, build_rule_case, build_separable_case, load_golden, oracle_forward, strict_share
 
 pytestmark = pytest.mark.gpu
 
@@ -1560,6 +1560,41 @@ def test_separable_detections_strictly_vs_reference():
     assert dbox.max() <= 0.05
 
 
+@pytest.mark.parametrize("seed", C.RULE_SEEDS)
+def test_rule_selected_detections_strictly_vs_reference(seed):
+    """Detection-level bf16 parity on cases chosen by a RULE that looks at the reference's fp32 outputs only (VERDICT r3 item 6;
+    tests/_cases.py::RULE / rule_verdict, goldens full_spp_640_rule_<seed>.npz generated from the reference by
+    tests/golden/make_golden.py --only rule; tests/test_oracle_golden.py proves the committed seeds are the FIRST ones that
+    qualify).  YOLOv3-SPP 640x640, 120 colour patches, head BN calibrated from the reference's raw heads so that every objectness
+    cut lies in a gap of >= 8 bf16 drifts of the normalised conv output.  WITHOUT guard band or noise re-runs:
+      * bf16 (the benched path): every reference detection has a bf16 partner and vice versa - same class, IoU >= 0.9,
+        |dconf| <= 0.03 (strict share >= 0.95 in both directions), same count;
+      * fp32 mode: the kept-index set IS the reference's, conf / class to 2e-4, boxes to 0.05 px."""
+    from pytorch_yolo_amd.utils.utils import non_max_suppression
+    rule = C.RULE
+    model, sd, x, g = build_rule_case(seed)
+    ref = g["nms_dets_0"]
+    model = model.to(DEV)
+    with torch.no_grad():
+        io16, _ = model(x.to(DEV))
+        dets16, _ = non_max_suppression(io16, rule["conf_thres"], rule["nms_thres"], with_indices=True)
+    d16 = dets16[0].cpu().numpy()
+    a, b = strict_share(ref, d16), strict_share(d16, ref)
+    dconf = max(min(abs(float(r[4]) - float(q[4])) for q in d16 if int(q[6]) == int(r[6])) if any(int(q[6]) == int(r[6]) for q in d16) else 1.0 for r in ref)
+    print(f"[rule case {seed}] reference {len(ref)} detections, bf16 {len(d16)}; strict share (IoU 0.9, dconf 0.03) {a:.3f} / {b:.3f}; "
+          f"largest conf distance of a reference detection to its class mate {dconf:.4f}")
+    assert min(a, b) >= 0.95 and len(d16) == len(ref)
+    model.precision = "fp32"
+    with torch.no_grad():
+        io32, _ = model(x.to(DEV))
+        dets32, idx32 = non_max_suppression(io32, rule["conf_thres"], rule["nms_thres"], with_indices=True)
+    d32, k32 = dets32[0].cpu().numpy(), idx32[0].cpu().numpy()
+    assert np.array_equal(k32, g["nms_kept_0"]), "fp32 mode: kept-index set differs from the reference's"
+    assert np.array_equal(d32[:, 6], ref[:, 6])
+    np.testing.assert_allclose(d32[:, 4:6], ref[:, 4:6], rtol=0, atol=2e-4)
+    assert np.abs(d32[:, :4] - ref[:, :4]).max() <= 0.05
+
+
 def test_bf16_path_within_its_rounding_budget():
     """SPP-640 at full size: the distance of the HIP bf16 forward to the fp32 reference must be the distance that bf16
     operand rounding alone produces — the oracle re-run under the fast path's rounding policy (oracle/policy.py: BN folded
@@ -1767,9 +1802,11 @@ def test_benched_list_diverges_only_where_the_summation_order_does():
             diverged = True
             d = (a.float() - b.float()).abs()
             share = float((d != 0).float().mean())
-            ulp = float((d / a.float().abs().clamp_min(2.0 ** -120)).max())
-            print(f"[list diff] launches 0..{i - 1} bit-equal; launch {i} ({names[0]} vs {names[1]}): {100 * share:.3f} % of the outputs differ, by at most {ulp:.4f} relative")
-            assert share <= 2e-3 and ulp <= 2.0 ** -7, "the first diverging launch differs by more than single bf16 roundings"
+            # one bf16 rounding step of the larger value; values next to zero are sums that cancel, whose fp32 order noise
+            # (~1e-6 of the terms' magnitude) is many of THEIR ulps: those get an absolute allowance of 1e-4 of the tensor's maximum
+            excess = float((d - (2.0 ** -7 * torch.maximum(a.float().abs(), b.float().abs()) + 1e-4 * float(a.float().abs().max()))).max())
+            print(f"[list diff] launches 0..{i - 1} bit-equal; launch {i} ({names[0]} vs {names[1]}): {100 * share:.3f} % of the outputs differ, max abs {float(d.max()):.4g}")
+            assert share <= 2e-3 and excess <= 0.0, "the first diverging launch differs by more than single bf16 roundings"
             break
     assert diverged and checked_equal >= 20
 
@@ -1864,7 +1901,9 @@ def test_launch_lists_stay_inside_their_buffers(name, monkeypatch):
         x.copy_(x_plain)
         with torch.no_grad():
             plan._launch(x, io, ps)
-            K.nms_merge(io, C.NMS_FULL["conf_thres"], C.NMS_FULL["nms_thres"], dets, idx, cnt, ws, min_wh=MIN_WH, max_per_class=MAX_PER_CLASS)
+            # (the MobileNetV2 model's uncalibrated synthetic heads score low: a threshold its survivors clear, so that the NMS kernels run)
+            K.nms_merge(io, 0.002 if name.startswith("mobile") else C.NMS_FULL["conf_thres"], C.NMS_FULL["nms_thres"], dets, idx, cnt, ws,
+                        min_wh=MIN_WH, max_per_class=MAX_PER_CLASS)
         torch.cuda.synchronize()
         return plan, ts, io, ps, dets, cnt
 

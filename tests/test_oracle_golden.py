@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import _cases as C
-from helpers import build_case, build_separable_case, load_golden, oracle_forward, strict_share
+from helpers import build_case, build_rule_case, build_separable_case, load_golden, oracle_forward, strict_share
 from oracle import blocks as ob
 from oracle import nms as onms
 
@@ -113,6 +113,45 @@ def test_separable_full_size_case():
     io_b, _ = run_policy(om.spp_forward, sd, x, C.SPP_ANCHORS, 80, policy="bf16")
     db, _ = onms.non_max_suppression(io_b.numpy().copy(), sep["conf_thres"], sep["nms_thres"])
     assert strict_share(g["nms_dets_0"], db[0]) == 1.0 and strict_share(db[0], g["nms_dets_0"]) == 1.0
+
+
+def test_rule_selected_cases_are_what_the_rule_selects():
+    """tests/_cases.py::RULE_SEEDS (VERDICT r3 item 6): (1) scanning patch-image seeds upward from 1, the committed seeds are exactly
+    the first len(RULE_SEEDS) that satisfy ``rule_verdict`` on the fp32 path's own outputs - no seed was skipped, none chosen by
+    what a bf16 run makes of it; (2) per committed case the oracle reproduces the reference golden (sampled io rows bit-equal, NMS
+    kept set / conf / class bit-equal), the stored head BN is ``calibrate_rule_heads`` applied to the un-calibrated raw heads, every
+    cut gap is >= 8 drifts, no conf lies within 0.05 of the threshold and the detections are tie-free."""
+    from oracle import models as om
+    from pytorch_yolo_amd import YOLOv3SPP
+    from pytorch_yolo_amd.utils.synthetic import synth_state_dict
+    rule = C.RULE
+    sd0 = synth_state_dict(YOLOv3SPP(anchors=C.SPP_ANCHORS).state_dict(), rule["weight_seed"], n_class=80)
+    qualifying = []
+    seed = 0
+    while len(qualifying) < len(C.RULE_SEEDS):
+        seed += 1
+        assert seed <= max(C.RULE_SEEDS), "a committed seed does not qualify, or an earlier qualifying seed was skipped"
+        x = torch.from_numpy(C.patch_image(seed, rule["n_patches"]))
+        with torch.no_grad():
+            _, p0 = om.spp_forward(sd0, x, C.SPP_ANCHORS, 80)
+            sd, gaps = C.rule_state_dict(sd0, [t[0].numpy() for t in p0], rule)
+            io, _ = om.spp_forward(sd, x, C.SPP_ANCHORS, 80)
+        ok, why = C.rule_verdict(io.numpy()[0], gaps, rule)
+        if not ok:
+            continue
+        qualifying.append(seed)
+        g = load_golden(f"full_spp_640_rule_{seed}")
+        assert np.array_equal(io.numpy()[:, g["rows"]], g["io_rows"]), "oracle differs from the reference on a rule case"
+        for k, h in enumerate(C.SEPARABLE_HEADS):
+            assert np.array_equal(sd[h + ".sequence.batch_norm.weight"].numpy(), g[f"head_bn_weight_{k}"])
+            assert np.array_equal(sd[h + ".sequence.batch_norm.bias"].numpy(), g[f"head_bn_bias_{k}"])
+        live = [v for v in gaps if v is not None]
+        assert min(live) >= rule["min_gap_drifts"] * rule["drift"] and np.allclose([-1.0 if v is None else v for v in gaps], g["cut_gaps"])
+        dets, kept = onms.non_max_suppression(io.numpy().copy(), rule["conf_thres"], rule["nms_thres"])
+        _check_nms(dets, kept, g, "nms_")
+        conf = g["nms_dets_0"][:, 4]
+        assert len(conf) >= rule["min_detections"] and len(np.unique(conf)) == len(conf) and conf.min() > rule["conf_thres"] + rule["conf_band"]
+    assert tuple(qualifying) == tuple(C.RULE_SEEDS)
 
 
 def _check_nms(dets, kept, g, prefix=""):
