@@ -277,6 +277,43 @@ def test_every_launch_stays_inside_the_plans_allocations(family, bs, hw, precisi
     assert checked == plan.n_ops
 
 
+def test_asm_mfma_kernels_keep_their_accumulator_distance(tmp_path):
+    """the 20x20-tile kernels (conv3x3_t20v2 / conv3x3s2_t20 / resunit64_t20 / resunit_t20w - 60 % of the headline's
+    launch time) issue their MFMAs as opaque ``asm volatile``, so LLVM's hazard recognizer does not pad around them and their
+    correctness rests on conventions in the source (s_nop runs behind the loops, accumulators that start as MFMA results).  This
+    test inspects the ISA hipcc actually emits (tools/isa_hazards.py): behind EVERY asm MFMA of every instantiation no non-MFMA
+    instruction reads or writes its accumulator registers within 11 wait states (LLVM's own padding for an 8-pass MFMA; the need
+    measured on MI355X is 7 for a read, 4 for a write: tools/micro/mfma_war.hip, profiles/r04_mfma_hazard_probe.txt), and the
+    same accumulator is not reused by another MFMA within 4.  A compiler update or an edit that moves a VALU instruction next to
+    the MFMAs fails here, on the CPU, instead of as 1 % wrong values under load.  The analyser is first shown to see a planted hazard."""
+    import importlib.util
+    from concurrent.futures import ThreadPoolExecutor
+    spec = importlib.util.spec_from_file_location("isa_hazards", os.path.join(ROOT, "tools", "isa_hazards.py"))
+    H = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(H)
+    planted = tmp_path / "planted.s"
+    planted.write_text("_Z4testv:\n\tv_mfma_f32_16x16x32_bf16 v[0:3], v[4:7], v[8:11], v[0:3]\n\ts_nop 2\n\tv_add_f32_e32 v20, v1, v21\n"
+                       "\tv_mfma_f32_16x16x32_bf16 v[0:3], v[4:7], v[8:11], v[0:3]\n\ts_nop 15\n\ts_nop 15\n\tv_mov_b32_e32 v9, 0\n\ts_endpgm\n.Lfunc_end0:\n")
+    n, best = H.analyse(H.parse(str(planted))["_Z4testv"])
+    assert n == 2 and best["d_touch"][0] == 3 and best["d_reuse"][0] == 4 and best["war_valu"][0] == 32
+    csrc = os.path.join(ROOT, "pytorch_yolo_amd", "csrc")
+    files = ["conv3x3_t20.hip", "conv_resunit_t20.hip"]
+    with ThreadPoolExecutor(2) as pool:
+        outs = list(pool.map(lambda f: H.device_asm(os.path.join(csrc, f), str(tmp_path / (f + ".s"))), files))
+    seen = 0
+    for path in outs:
+        for name, insts in H.parse(path).items():
+            n, best = H.analyse(insts)
+            if not n:
+                continue
+            seen += 1
+            assert n >= 400, f"{name}: {n} MFMAs - not the fully unrolled tile loop?"
+            assert best["d_touch"] is None or best["d_touch"][0] >= H.D_WINDOW, \
+                f"{name}: a non-MFMA instruction touches an accumulator {best['d_touch'][0]} wait states behind its MFMA (asm line {best['d_touch'][1]} -> {best['d_touch'][2]}: {best['d_touch'][3]})"
+            assert best["d_reuse"] is None or best["d_reuse"][0] >= 4, f"{name}: accumulator reused {best['d_reuse'][0]} wait states behind its MFMA"
+    assert seen == 10            # t20v2 x 2, t20s2 x 2, resunit_t20w x 4, resunit64_t20 x 2 (LeakyReLU fast path / generic activation)
+
+
 def test_planner_squeezenet_variant():
     """YOLOv3TinySqueeze (reference models/yolov3_tiny_squeeze.py): torchvision's SqueezeNet 1.1 key names, the
     unpadded first conv, ceil-mode pools and Fire modules that write their two expand convs into one concat buffer."""
