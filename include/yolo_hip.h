@@ -319,6 +319,40 @@ YOLO_API int yolo_stream_destroy(yolo_stream_t s);
  * while launching on it): grids are sized against it.  Returns the previous value (<0: argument error). */
 YOLO_API int yolo_set_launch_cus(int n_cu);
 
+/* ---- one pipelined detect() step with ONE FFI crossing (round 4): what pytorch_yolo_amd.engine.StreamedPlan.launch_detect does
+ *  for a whole-batch pipeline - the composition of reference utils/utils.py:374-378 (forward -> non_max_suppression) on a stream of
+ *  batches - as a single call, because at YOLOv3-tiny rates (0.37 ms per 32 images) the Python between the launches was the
+ *  bottleneck of detect_stream().  Order of what it enqueues:
+ *    stream:      [wait wait_x] ops[0 .. k_io) [wait wait_io] ops[k_io .. n_ops) ; record heads_done
+ *    nms_stream:  wait heads_done ; yolo_nms_merge(io ...) ; [count -> count_host, async] ; record nms_done ; [record done]
+ *  wait_x: "the input batch is ready" (recorded by the caller on the stream that produced x); wait_io: the nms_done of the step that
+ *  used this io buffer before (its NMS still reads io when the head launches - ops from k_io on - would overwrite it).
+ *  Events are yolo_event_t (hipEvent_t, timing disabled) from yolo_event_create; NULL = skip.  nms_stream may equal stream.
+ *  count_host: PINNED host memory for bs int32 (NULL: no copy): valid once `done` (or nms_done) has completed.
+ *  Nothing is synchronised on the host; buffers stay owned by the caller as everywhere else. */
+typedef void* yolo_event_t; /* hipEvent_t */
+YOLO_API int yolo_event_create(yolo_event_t* out);
+YOLO_API int yolo_event_destroy(yolo_event_t e);
+YOLO_API int yolo_event_record(yolo_event_t e, yolo_stream_t s);
+YOLO_API int yolo_event_synchronize(yolo_event_t e);
+typedef struct YoloPipeStep {
+  const YoloOp* ops; int32_t n_ops, k_io;
+  yolo_stream_t stream, nms_stream;
+  yolo_event_t wait_x, wait_io, heads_done, nms_done, done;
+  float* io; int32_t bs, rows, nc, max_per_class; float conf_thres, nms_thres, min_wh; int32_t cap;
+  float* out_dets; int32_t* out_idx; int32_t* out_count; void* workspace; size_t workspace_bytes;
+  int32_t* count_host;
+} YoloPipeStep;
+YOLO_API int yolo_pipeline_step(const YoloPipeStep* st);
+/* sizeof of the ABI's structs as the library was compiled (0 YoloConvDesc, 1 YoloOp, 2 YoloMbconvDesc, 3 YoloPipeStep; else -1):
+ * a binding checks its own layout against it. */
+YOLO_API int yolo_abi_sizeof(int which);
+/* The kept rows of all images packed back to back (the reference returns one [n_i, 7] tensor per image, utils.py:293): image b's
+ * min(count[b], cap) rows of dets [bs, cap, 7] go to packed rows [sum_{i<b} count'[i], ...), their pivot rows to packed_idx (nullable).
+ * One launch, offsets computed on the device from `count` (the host knows the total from its copy of the counts). */
+YOLO_API int yolo_pack_detections(const float* dets, const int32_t* idx, const int32_t* count, int bs, int cap, float* packed,
+                                  int64_t* packed_idx, yolo_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,10 +45,21 @@ class YoloMbconvDesc(C.Structure):
         "stride", "has_expand", "has_res", "_pad")]
 
 
+class YoloPipeStep(C.Structure):
+    _fields_ = [("ops", C.POINTER(YoloOp)), ("n_ops", C.c_int32), ("k_io", C.c_int32),
+                ("stream", C.c_void_p), ("nms_stream", C.c_void_p),
+                ("wait_x", C.c_void_p), ("wait_io", C.c_void_p), ("heads_done", C.c_void_p), ("nms_done", C.c_void_p), ("done", C.c_void_p),
+                ("io", C.c_void_p), ("bs", C.c_int32), ("rows", C.c_int32), ("nc", C.c_int32), ("max_per_class", C.c_int32),
+                ("conf_thres", C.c_float), ("nms_thres", C.c_float), ("min_wh", C.c_float), ("cap", C.c_int32),
+                ("out_dets", C.c_void_p), ("out_idx", C.c_void_p), ("out_count", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t), ("count_host", C.c_void_p)]
+
+
 # symbol -> (restype, argtypes); kept in one table so tests can check it against the header
 SIGNATURES = {
     "yolo_last_error": (C.c_char_p, []),
     "yolo_abi_version": (C.c_int, []),
+    "yolo_abi_sizeof": (C.c_int, [C.c_int]),
     "yolo_set_tuning": (C.c_int, [C.c_int, C.c_int]),
     "yolo_pack_input_nchw_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
     "yolo_conv2d_fwd": (C.c_int, [C.c_void_p] * 6 + [C.POINTER(YoloConvDesc), C.c_void_p]),
@@ -99,6 +110,12 @@ SIGNATURES = {
     "yolo_stream_create_cu_mask": (C.c_int, [C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_void_p)]),
     "yolo_stream_destroy": (C.c_int, [C.c_void_p]),
     "yolo_set_launch_cus": (C.c_int, [C.c_int]),
+    "yolo_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "yolo_event_destroy": (C.c_int, [C.c_void_p]),
+    "yolo_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "yolo_event_synchronize": (C.c_int, [C.c_void_p]),
+    "yolo_pipeline_step": (C.c_int, [C.POINTER(YoloPipeStep)]),
+    "yolo_pack_detections": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None
@@ -120,6 +137,9 @@ def load():
         fn.argtypes = args
     if lib.yolo_abi_version() != 1:
         raise RuntimeError("libyolo_hip.so ABI version mismatch")
+    for which, st in enumerate((YoloConvDesc, YoloOp, YoloMbconvDesc, YoloPipeStep)):
+        if lib.yolo_abi_sizeof(which) != C.sizeof(st):
+            raise RuntimeError(f"libyolo_hip.so: struct {st.__name__} is {lib.yolo_abi_sizeof(which)} bytes in the library, {C.sizeof(st)} in the binding")
     _lib = lib
     return lib
 

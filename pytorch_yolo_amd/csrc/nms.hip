@@ -461,6 +461,21 @@ __global__ __launch_bounds__(256) void scale_coords_kernel(float* __restrict__ d
   *v = x;
 }
 
+// kept rows of all images back to back: block b copies image b's rows behind the rows of the images before it
+__global__ __launch_bounds__(256) void pack_detections_kernel(const float* __restrict__ dets, const int* __restrict__ idx,
+                                                              const int* __restrict__ count, int cap, float* __restrict__ packed,
+                                                              long long* __restrict__ packed_idx) {
+  const int b = blockIdx.x;
+  int off = 0;
+  for (int i = 0; i < b; ++i) off += min(count[i], cap);
+  const int n = min(count[b], cap);
+  const float* src = dets + (long)b * cap * 7;
+  float* dst = packed + (long)off * 7;
+  for (int i = threadIdx.x; i < n * 7; i += 256) dst[i] = src[i];
+  if (packed_idx)
+    for (int i = threadIdx.x; i < n; i += 256) packed_idx[off + i] = idx[(long)b * cap + i];
+}
+
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 inline size_t pow2_at_least(size_t v) {
   size_t p = 1;
@@ -544,4 +559,12 @@ extern "C" int yolo_scale_coords(float* dets, int bs, int cap, int row_floats, c
   hipLaunchKernelGGL(scale_coords_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, dets,
                      row_floats, cap, (const float4*)params_dev, do_round, total);
   return yolo_check_launch("yolo_scale_coords");
+}
+
+extern "C" int yolo_pack_detections(const float* dets, const int32_t* idx, const int32_t* count, int bs, int cap, float* packed,
+                                    int64_t* packed_idx, yolo_stream_t s) {
+  YOLO_REQUIRE(dets && count && packed && bs > 0 && cap > 0 && (idx || !packed_idx), "pack_detections: bad arguments");
+  hipLaunchKernelGGL(pack_detections_kernel, dim3((unsigned)bs), dim3(256), 0, (hipStream_t)s, dets, idx, count, cap, packed,
+                     (long long*)packed_idx);
+  return yolo_check_launch("yolo_pack_detections");
 }

@@ -13,6 +13,15 @@ int yolo_set_error(int code, const char* fmt, ...) {
 
 extern "C" const char* yolo_last_error(void) { return g_err; }
 extern "C" int yolo_abi_version(void) { return 1; }
+extern "C" int yolo_abi_sizeof(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(YoloConvDesc);
+    case 1: return (int)sizeof(YoloOp);
+    case 2: return (int)sizeof(YoloMbconvDesc);
+    case 3: return (int)sizeof(YoloPipeStep);
+    default: return -1;
+  }
+}
 
 // A stream whose kernels run only on the compute units named in cu_mask (bit i = CU i; on MI355X bit i lies on XCD i % 8).
 // engine.StreamedPlan gives each sub-batch stream its own half of every XCD so two layer lists really run side by side.
@@ -108,5 +117,59 @@ extern "C" int yolo_run_ops(const YoloOp* ops, int n_ops, yolo_stream_t s) {
     }
     if (rc) return rc;
   }
+  return 0;
+}
+
+// ---- events and the one-call pipeline step (include/yolo_hip.h: yolo_pipeline_step) ------------------------------------------------
+#define YOLO_HIP_TRY(expr, what)                                                                   \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) return yolo_set_error((int)e_, "%s: %s", what, hipGetErrorString(e_));   \
+  } while (0)
+
+extern "C" int yolo_event_create(yolo_event_t* out) {
+  YOLO_REQUIRE(out, "event_create: null pointer");
+  hipEvent_t e = nullptr;
+  YOLO_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreateWithFlags");
+  *out = (yolo_event_t)e;
+  return 0;
+}
+extern "C" int yolo_event_destroy(yolo_event_t e) {
+  YOLO_REQUIRE(e, "event_destroy: null event");
+  YOLO_HIP_TRY(hipEventDestroy((hipEvent_t)e), "hipEventDestroy");
+  return 0;
+}
+extern "C" int yolo_event_record(yolo_event_t e, yolo_stream_t s) {
+  YOLO_REQUIRE(e, "event_record: null event");
+  YOLO_HIP_TRY(hipEventRecord((hipEvent_t)e, (hipStream_t)s), "hipEventRecord");
+  return 0;
+}
+extern "C" int yolo_event_synchronize(yolo_event_t e) {
+  YOLO_REQUIRE(e, "event_synchronize: null event");
+  YOLO_HIP_TRY(hipEventSynchronize((hipEvent_t)e), "hipEventSynchronize");
+  return 0;
+}
+
+extern "C" int yolo_pipeline_step(const YoloPipeStep* st) {
+  YOLO_REQUIRE(st && st->ops && st->n_ops > 0 && st->k_io >= 0 && st->k_io <= st->n_ops, "pipeline_step: bad op list");
+  YOLO_REQUIRE(st->heads_done && st->nms_done, "pipeline_step: heads_done / nms_done events are required");
+  hipStream_t s = (hipStream_t)st->stream, ns = (hipStream_t)st->nms_stream;
+  if (st->wait_x) YOLO_HIP_TRY(hipStreamWaitEvent(s, (hipEvent_t)st->wait_x, 0), "hipStreamWaitEvent(x)");
+  int rc = yolo_run_ops(st->ops, st->k_io, st->stream);
+  if (rc) return rc;
+  if (st->wait_io) YOLO_HIP_TRY(hipStreamWaitEvent(s, (hipEvent_t)st->wait_io, 0), "hipStreamWaitEvent(io)");
+  rc = yolo_run_ops(st->ops + st->k_io, st->n_ops - st->k_io, st->stream);
+  if (rc) return rc;
+  if (ns != s) {
+    YOLO_HIP_TRY(hipEventRecord((hipEvent_t)st->heads_done, s), "hipEventRecord(heads)");
+    YOLO_HIP_TRY(hipStreamWaitEvent(ns, (hipEvent_t)st->heads_done, 0), "hipStreamWaitEvent(heads)");
+  }
+  rc = yolo_nms_merge(st->io, st->bs, st->rows, st->nc, st->conf_thres, st->nms_thres, st->min_wh, st->max_per_class, 0, st->out_dets,
+                      st->out_idx, st->out_count, st->cap, st->workspace, st->workspace_bytes, st->nms_stream);
+  if (rc) return rc;
+  if (st->count_host)
+    YOLO_HIP_TRY(hipMemcpyAsync(st->count_host, st->out_count, (size_t)st->bs * 4, hipMemcpyDeviceToHost, ns), "hipMemcpyAsync(count)");
+  YOLO_HIP_TRY(hipEventRecord((hipEvent_t)st->nms_done, ns), "hipEventRecord(nms)");
+  if (st->done) YOLO_HIP_TRY(hipEventRecord((hipEvent_t)st->done, ns), "hipEventRecord(done)");
   return 0;
 }

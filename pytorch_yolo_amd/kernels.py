@@ -360,5 +360,40 @@ def set_launch_cus(n_cu: int) -> int:
     return old
 
 
+class Event:
+    """A HIP event owned by this library's C side (yolo_event_*): no timing, recorded / waited for by yolo_pipeline_step."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        check(load().yolo_event_create(C.byref(h)), "event_create")
+        self.handle = h.value
+
+    def record(self, stream: int = None):
+        check(load().yolo_event_record(self.handle, stream_ptr() if stream is None else stream), "event_record")
+
+    def synchronize(self):
+        check(load().yolo_event_synchronize(self.handle), "event_synchronize")      # (ctypes releases the GIL while it waits)
+
+    def __del__(self):
+        try:
+            load().yolo_event_destroy(self.handle)
+        except Exception:                                   # noqa: BLE001 (interpreter teardown)
+            pass
+
+
+def pipeline_step(step):
+    check(load().yolo_pipeline_step(C.byref(step)), "pipeline_step")
+
+
+def pack_detections(dets, idx, count, packed, packed_idx=None):
+    """Kept rows of all images back to back (yolo_pack_detections): dets [bs, cap, 7], count int32 [bs] on the device -> packed
+    [total, 7] (+ packed_idx int64 [total] from idx int32 [bs, cap])."""
+    _need_cuda(dets, count, packed, idx, packed_idx)
+    bs, cap = dets.shape[0], dets.shape[1]
+    check(load().yolo_pack_detections(_ptr(dets), _ptr(idx), _ptr(count), bs, cap, _ptr(packed), _ptr(packed_idx), stream_ptr()),
+          "pack_detections")
+    return packed
+
+
 def run_ops(op_array, n_ops: int):
     check(load().yolo_run_ops(op_array, n_ops, stream_ptr()), "run_ops")

@@ -231,10 +231,12 @@ class YOLOBase(nn.Module):
                 return plan.run_graph(x)
             return plan.run(x)
 
-    def detect_stream(self, batches, conf_thres=0.5, nms_thres=0.5):
+    def detect_stream(self, batches, conf_thres=0.5, nms_thres=0.5, depth=None):
         """``detect()`` over a stream of equally shaped batches with the GPU kept busy: a generator that yields, in order, the
-        reference-style ``list[Tensor[n,7] | None]`` of every batch - batch k's list after batch k+S-1 has been launched (S = the
-        plan's pipelines, 2 by default).  Successive batches alternate between the pipelines (``launch_detect(whole_batch=True)``):
+        reference-style ``list[Tensor[n,7] | None]`` of every batch - batch k's list after batch k+depth-1 has been launched.
+        ``depth`` = batches in flight (their output buffers form a ring): default S = the plan's pipelines (2) for models whose
+        batch keeps the GPU busy for milliseconds, 2 S for the small ones (< 1 TFLOP per batch: a YOLOv3-tiny batch takes 0.37 ms,
+        and with only S in flight a pipeline idles while the host hands out one batch and launches the next).  Successive batches alternate between the pipelines (``launch_detect(whole_batch=True)``):
         no host sync per batch except the count read-back of the batch being handed out, which by then has left the GPU.  The
         pipelines share the chip (no CU partition: ``launch_detect(cu_partition=...)`` says why).
         SPP-640 x 32: ~6,000 images/s against ~4,700 for back-to-back ``detect()`` calls (bench.py)."""
@@ -252,15 +254,26 @@ class YOLOBase(nn.Module):
                 if shape is None:
                     shape, dev = tuple(x.shape), x.device
                     plan = self.plan_for(x)
-                    depth = max(2, plan.n_streams)
+                    if depth is None:
+                        depth = max(2, plan.n_streams) * (2 if plan.conv_flops() < 1e12 else 1)
+                    depth = max(2, int(depth))
                     cap = nms_capacity(plan.rows_total, self.n_class)
+                    # the ring (output buffers, pinned count buffers, events, prebuilt pipeline steps) of the last generator that
+                    # finished on this plan is taken over: building one costs more than 40 YOLOv3-tiny batches take
+                    pool = plan.__dict__.setdefault("_stream_rings", {})
+                    ring = pool.pop(depth, None) or []
+                    for item in ring:
+                        if item[4] is not None:
+                            item[4].step.conf_thres, item[4].step.nms_thres = float(conf_thres), float(nms_thres)
                     with torch.cuda.device(x.device):
-                        for _ in range(depth):
+                        for slot in range(0 if ring else depth):
                             io, ps = plan.new_outputs(want_p=False)
                             out = (torch.empty((shape[0], cap, 7), dtype=torch.float32, device=x.device),
                                    torch.empty((shape[0], cap), dtype=torch.int32, device=x.device),
                                    torch.empty((shape[0],), dtype=torch.int32, device=x.device))
-                            ring.append((io, ps, out, torch.cuda.Event()))
+                            # one FFI call per batch where the plan allows it (engine.FastStep: yolo_pipeline_step)
+                            fast = plan.fast_pipeline(slot, io, out, conf_thres, nms_thres) if hasattr(plan, "fast_pipeline") else None
+                            ring.append((io, ps, out, torch.cuda.Event(), fast))
                 elif tuple(x.shape) != shape or x.device != dev:
                     raise RuntimeError(f"detect_stream: batch {tuple(x.shape)} on {x.device} differs from the first one "
                                        f"{shape} on {dev}")
@@ -268,11 +281,14 @@ class YOLOBase(nn.Module):
                     yield self._collect(pending.pop(0))
                 k = self.__dict__.setdefault("_stream_calls", 0)
                 self._stream_calls = k + 1
-                io, ps, out, done = ring[k % len(ring)]
+                io, ps, out, done, fast = ring[k % len(ring)]
                 with torch.cuda.device(x.device):
+                    pending.append((x, out, done, fast))         # (before the launch: a launch that fails half way is drained too)
+                    if fast is not None:
+                        fast.launch(x)
+                        continue
                     ready = torch.cuda.Event()
                     ready.record()                               # x was produced on the caller's stream: the pipeline waits for it
-                    pending.append((x, out, done))               # (before the launch: a launch that fails half way is drained too)
                     plan.launch_detect(x, io, ps, out, conf_thres, nms_thres, join=False, whole_batch=True, wait_for=ready,
                                        after_nms=lambda i, lo, hi, done=done: done.record(torch.cuda.current_stream()))
             while pending:
@@ -281,11 +297,15 @@ class YOLOBase(nn.Module):
             if pending and dev is not None:                      # abnormal exit with batches in flight: drain before ring dies
                 torch.cuda.synchronize(dev)
                 pending.clear()
+            if plan is not None and ring and len(ring) == depth:
+                plan.__dict__.setdefault("_stream_rings", {})[depth] = ring      # drained: the next generator on this plan reuses it
 
     @staticmethod
     def _collect(item):
         from ..utils.utils import split_detections
-        _, out, done = item
+        _, out, done, fast = item
+        if fast is not None:
+            return fast.collect()
         done.synchronize()
         return split_detections(*out)
 
@@ -298,6 +318,10 @@ class YOLOBase(nn.Module):
         x = x.float().contiguous()
         plan = self.plan_for(x)
         with torch.cuda.device(x.device):
+            fast = plan.detect_step(conf_thres, nms_thres) if hasattr(plan, "detect_step") else None
+            if fast is not None:                             # one whole-batch launch list + NMS behind ONE FFI call (engine.FastStep)
+                fast.launch(x)
+                return fast.collect()
             io, ps = plan.new_outputs(want_p=False)          # NMS reads io only: the raw head tensors are not materialised
             bs, cap = x.shape[0], nms_capacity(plan.rows_total, self.n_class)
             out = (torch.empty((bs, cap, 7), dtype=torch.float32, device=x.device),

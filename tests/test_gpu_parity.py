@@ -1659,6 +1659,11 @@ def test_headline_config_bs32_two_streams():
             _assert_model_close(io_c[i:i + 1], io_ref, f"spp_640x32 image {i} vs fp32 oracle", score_max=0.225, score_rms=1e-2)       # measured over images 0 / 13 / 31: 0.140 / 0.178 / 0.180 (+ 25 %)
         model.n_streams = 2
         dets = model.detect(xd, **C.NMS_FULL)
+        # (round 4) a lone detect() runs ONE whole-batch list (engine.StreamedPlan.detect_step): the oracle NMS gets the io that
+        # call produced (test_benched_launch_list_bs32_whole_batch holds that list against the reference)
+        fast = model.plan_for(xd).detect_step(**C.NMS_FULL)
+        assert fast is not None and fast._launched
+        io_c = fast.io.cpu()
     odets, _ = onms.non_max_suppression(io_c.numpy().copy(), **C.NMS_FULL)
     for b in range(32):
         assert (dets[b] is None) == (odets[b] is None)
@@ -2475,9 +2480,11 @@ def test_detect_stream_yields_every_batch_in_order():
     # the API pipelines must not run on CU-masked streams: HIP creates those as blocking streams, and the default-stream operations of
     # a serving loop (the "x is ready" event, the H2D copies above) would then serialise the two pipelines on half the chip each
     assert model.plan_for(host[0].to(DEV))._full_streams is None
+    # ... and they took the one-call pipeline step (yolo_pipeline_step through engine.FastStep), not the Python launch sequence
+    assert model.plan_for(host[0].to(DEV))._fast_events is not None
     def idle():      # nothing of a dropped generator may still be running: its output ring goes back to the allocator
         plan = model.plan_for(host[0].to(DEV))
-        sts = list(plan.streams) + list(plan._full_streams or []) + [plan._nms_stream]
+        sts = list(plan.streams) + list(plan._full_streams or []) + list(plan._nms_streams or [])
         return all(st is None or st.query() for st in sts)
     with pytest.raises(RuntimeError):
         list(model.detect_stream([host[0].to(DEV), host[0][:4].to(DEV)], 1e-4, 0.5))

@@ -47,6 +47,12 @@ def test_struct_layout_matches_header():
     body = text[text.index("typedef struct YoloConvDesc {"):text.index("} YoloConvDesc;")]
     fields = re.findall(r"\b([a-z_0-9]+)\s*[,;]", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
     assert fields == [f for f, _ in _lib.YoloConvDesc._fields_]
+    # the pipeline step (round 4): field order as declared, size as the library compiled it
+    body = text[text.index("typedef struct YoloPipeStep {"):text.index("} YoloPipeStep;")]
+    fields = re.findall(r"\b([a-z_0-9]+)\s*[,;]", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
+    assert fields == [f for f, _ in _lib.YoloPipeStep._fields_]
+    for which, st in enumerate((_lib.YoloConvDesc, _lib.YoloOp, _lib.YoloMbconvDesc, _lib.YoloPipeStep)):
+        assert _lib.load().yolo_abi_sizeof(which) == ctypes.sizeof(st)
 
 
 def test_argument_errors_are_reported_without_a_gpu():
