@@ -243,6 +243,9 @@ def main():
     ap.add_argument("--pipeline", default="batches", choices=["batches", "halves"],
                     help="what a pipeline carries: whole batches, successive steps alternating between the pipelines (default), or "
                          "one sub-batch of every step each")
+    ap.add_argument("--materialize-io", action="store_true",
+                    help="store io and run the plain NMS on it (A/B of the compact NMS form, which is the default: the heads filter "
+                         "their own rows and detect() never writes io)")
     ap.add_argument("--no-api", action="store_true", help="skip the API-level model.detect() timing")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2.5 s sustained-rate window after the timed region")
     ap.add_argument("--dry-run", action="store_true",
@@ -333,10 +336,11 @@ def main():
         calls[0] += 1
         tm = ev[i] if timed else None
         if gatherer is None:
-            plan.launch_detect(x, io, ps, nms_out, CONF_THRES, NMS_THRES, timing=tm, join=False, whole_batch=whole, cu_partition=True)
+            plan.launch_detect(x, io, ps, nms_out, CONF_THRES, NMS_THRES, timing=tm, join=False, whole_batch=whole, cu_partition=True,
+                               compact=not args.materialize_io)
             return nms_out[0], nms_out[2]
         plan.launch_detect(x, io, ps, nms_out, CONF_THRES, NMS_THRES, timing=tm, join=False, whole_batch=whole,
-                           after_nms=gatherer.begin(nms_out))
+                           after_nms=gatherer.begin(nms_out), compact=not args.materialize_io)
         all_dets, all_count, _ = gatherer.exchange()
         return all_dets, all_count
 
@@ -456,6 +460,8 @@ def main():
                "mean_detections_per_image": round(sum(n_dets) / max(1, len(n_dets)), 1),
                "streams_per_gpu": n_streams, "precision": model.precision}
         cfg["raw_head_tensors_p"] = "not materialised: detect() discards them (forward() stores them; tests cover both)"
+        cfg["decoded_rows_io"] = ("materialised (--materialize-io): the plain NMS reads them back" if args.materialize_io else
+                                  "not materialised: the head epilogues filter their own rows into the NMS workspace (compact form); forward() stores them")
         if n_streams > 1:
             cfg["pipelines"] = (f"{n_streams} x whole batches of {bs} (successive steps alternate)" if whole
                                 else f"{n_streams} x sub-batches of {bs // n_streams} of every step")

@@ -242,6 +242,23 @@ YOLO_API int yolo_nms_merge(float* pred, int bs, int rows, int nc, float conf_th
                    int max_per_class, int mutate_conf, float* out_dets, int32_t* out_idx,
                    int32_t* out_count, int cap, void* workspace, size_t workspace_bytes, yolo_stream_t s);
 
+/* ---- the compact form of the same post-process (round 4): detect() = non_max_suppression(forward(x)[0]) without ever writing io.
+ *  The head convs filter their own decoded rows in their epilogue (yolo_head_decode_filter_fwd: the row filter of utils.py:212-218,
+ *  operation for operation what yolo_nms_merge's first kernel does on a materialised io) and leave, in the workspace, ONE sort key
+ *  per io row (~0 for a row that does not survive) plus a 32-byte record (x, y, w, h, class score) for the survivors; no atomics and
+ *  nothing to initialise - every io row belongs to exactly one head.  yolo_nms_merge_compact gathers the keys and runs the same
+ *  sort / MERGE / final order.  Saves the io store and its read-back (2 x 274 MB per 32 SPP-640 images) and one launch; the
+ *  detections are bit-equal to yolo_nms_merge on the io the plain heads would have written.  Order per batch, on one stream or on
+ *  ordered streams:  every head's yolo_head_decode_filter_fwd (together they must cover all `rows`) -> yolo_nms_merge_compact. */
+YOLO_API size_t yolo_nms_compact_workspace_bytes(int bs, int rows, int nc);
+YOLO_API int yolo_head_decode_filter_fwd(const void* x, const void* w_packed, const float* bias, const YoloConvDesc* d,
+                                         const float* anchors_px, int na, int nc, float stride_px, int io_rows_total,
+                                         int io_row_offset, float conf_thres, float min_wh, void* workspace, size_t workspace_bytes,
+                                         float* p, yolo_stream_t s);
+YOLO_API int yolo_nms_merge_compact(void* workspace, size_t workspace_bytes, int bs, int rows, int nc, float nms_thres,
+                                    int max_per_class, float* out_dets, int32_t* out_idx, int32_t* out_count, int cap,
+                                    yolo_stream_t s);
+
 /* ---- scale_coords (utils/utils.py:296-303): map kept boxes from the network-input frame back to each original
  *  image: dets [bs,cap,row_floats] (columns 0..3 = x1,y1,x2,y2) in place; params_dev: device f32 [bs][4] =
  *  {pad_x, pad_y, gain, n_rows}; do_round = the `.round()` of the caller at utils.py:313. */
@@ -298,15 +315,16 @@ typedef struct YoloOp {
                                     res_c_total = real input channels, see yolo_stem_fwd */
   const void* w_pre; const float* bias_pre;   /* RESUNIT / STEM: packed W1 / b1 of the leading conv */
   int32_t kpad_pre, cout_pad_pre;
-  /* HEAD_DECODE (yolo_head_decode_fwd): y = io, y_aux = p (nullable), conv = the head conv */
+  /* HEAD_DECODE (yolo_head_decode_fwd): y = io, y_aux = p (nullable), conv = the head conv.  y == NULL with workspace set:
+     yolo_head_decode_filter_fwd into the compact NMS workspace (workspace / ws_bytes), thresholds head_filter_conf / head_filter_min_wh */
   float head_anchors_px[8]; float head_stride_px;
-  int32_t head_na, head_nc, io_rows_total, io_row_offset, _pad2;
+  int32_t head_na, head_nc, io_rows_total, io_row_offset; float head_filter_conf;
   /* MBCONV (yolo_mbconv_fwd): w/bias = W_proj/b_proj, w_pre/bias_pre = W_expand/b_expand (NULL: no expand conv),
      w_dw/bias_dw = the depthwise conv; geometry from conv (n,h,w,cin,views,cout,stride), hidden = kpad_pre,
      has_res = conv.res_c_total != 0 */
   const float* w_dw; const float* bias_dw;
   /* CONV with splits >= 2: yolo_conv2d_splitk_fwd */
-  void* workspace; int32_t* counters; size_t ws_bytes; int32_t splits, _pad3;
+  void* workspace; int32_t* counters; size_t ws_bytes; int32_t splits; float head_filter_min_wh;
 } YoloOp;
 YOLO_API int yolo_run_ops(const YoloOp* ops, int n_ops, yolo_stream_t s);
 
@@ -328,6 +346,8 @@ YOLO_API int yolo_set_launch_cus(int n_cu);
  *  wait_x: "the input batch is ready" (recorded by the caller on the stream that produced x); wait_io: the nms_done of the step that
  *  used this io buffer before (its NMS still reads io when the head launches - ops from k_io on - would overwrite it).
  *  Events are yolo_event_t (hipEvent_t, timing disabled) from yolo_event_create; NULL = skip.  nms_stream may equal stream.
+ *  io == NULL selects the compact form: `workspace` is a yolo_nms_compact_workspace_bytes one, the head ops (already bound to it,
+ *  YoloOp) filter into it behind wait_io and the NMS is yolo_nms_merge_compact.
  *  count_host: PINNED host memory for bs int32 (NULL: no copy): valid once `done` (or nms_done) has completed.
  *  Nothing is synchronised on the host; buffers stay owned by the caller as everywhere else. */
 typedef void* yolo_event_t; /* hipEvent_t */

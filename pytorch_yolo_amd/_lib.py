@@ -33,10 +33,10 @@ class YoloOp(C.Structure):
                 ("w_pre", C.c_void_p), ("bias_pre", C.c_void_p), ("kpad_pre", C.c_int32), ("cout_pad_pre", C.c_int32),
                 ("head_anchors_px", C.c_float * 8), ("head_stride_px", C.c_float),
                 ("head_na", C.c_int32), ("head_nc", C.c_int32), ("io_rows_total", C.c_int32),
-                ("io_row_offset", C.c_int32), ("_pad2", C.c_int32),
+                ("io_row_offset", C.c_int32), ("head_filter_conf", C.c_float),
                 ("w_dw", C.c_void_p), ("bias_dw", C.c_void_p),
                 ("workspace", C.c_void_p), ("counters", C.c_void_p), ("ws_bytes", C.c_size_t),
-                ("splits", C.c_int32), ("_pad3", C.c_int32)]
+                ("splits", C.c_int32), ("head_filter_min_wh", C.c_float)]
 
 
 class YoloMbconvDesc(C.Structure):
@@ -99,6 +99,11 @@ SIGNATURES = {
     "yolo_nms_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
     "yolo_nms_merge": (C.c_int, [C.c_void_p] + [C.c_int] * 3 + [C.c_float] * 3 + [C.c_int] * 2 +
                        [C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "yolo_nms_compact_workspace_bytes": (C.c_size_t, [C.c_int] * 3),
+    "yolo_head_decode_filter_fwd": (C.c_int, [C.c_void_p] * 3 + [C.POINTER(YoloConvDesc), C.c_void_p, C.c_int, C.c_int, C.c_float,
+                                              C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "yolo_nms_merge_compact": (C.c_int, [C.c_void_p, C.c_size_t] + [C.c_int] * 3 + [C.c_float, C.c_int] + [C.c_void_p] * 3 +
+                               [C.c_int, C.c_void_p]),
     "yolo_scale_coords": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "yolo_letterbox_u8_fwd": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_double] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p] +
                               [C.c_int] * 4 + [C.c_float, C.c_void_p]),

@@ -269,12 +269,17 @@ __global__ __launch_bounds__(256) void conv1_nchw_kernel(const ConvArgs a, const
 #pragma unroll
   for (int g4 = 0; g4 < 4; ++g4) bias4[g4] = *reinterpret_cast<const f32x4*>(a.bias + g4 * 8 + khalf * 4);
 
-  // halo pixels owned by this thread (2 of the 324), prefetched one tile ahead into registers
+  // halo pixels owned by this thread (2 of the 324).  Round 4: the halos of ALL the block's tiles are requested up front (TPB x 2
+  // pixels x cin_real floats in registers; CINR == 3: 30 registers) instead of one tile ahead: with one tile in flight a workgroup
+  // had 3.9 KB outstanding - 16 KB per CU at four workgroups -, and the layer (read 12 B, write 32 B per pooled pixel: HBM traffic,
+  // not MFMA work) ran at 1.1 TB/s, a latency chain of one HBM round trip per tile.  Vector-memory operations return in issue order,
+  // so tile t's commit waits for tile t's loads only.
   const long plane = (long)d.h * d.w;
   const int hp0 = tid, hp1 = tid + 256;
   const int hy0 = hp0 / HW2, hx0 = hp0 - hy0 * HW2, hy1 = hp1 / HW2, hx1 = hp1 - hy1 * HW2;
-  float pre[2][8];
-  auto fetch = [&](int t) {
+  constexpr int NCH = CINR ? CINR : 8;
+  float pre[TPB][2][NCH];
+  auto fetch = [&](int t, float (&dst)[2][NCH]) {
     const int x0 = (tx0 + t) * 16;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -283,28 +288,31 @@ __global__ __launch_bounds__(256) void conv1_nchw_kernel(const ConvArgs a, const
       const bool ok = (u == 0 || hp1 < HP) && (unsigned)yy < (unsigned)d.h && (unsigned)xx < (unsigned)d.w;
       const float* src = x_nchw + ((long)b * cin_real) * plane + (long)yy * d.w + xx;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) pre[u][e] = (ok && e < cin_real) ? src[e * plane] : 0.f;
+      for (int e = 0; e < NCH; ++e) dst[u][e] = (ok && e < cin_real) ? src[e * plane] : 0.f;
     }
   };
-  auto commit = [&](int hb) {                                  // registers -> LDS halo buffer as NHWC8 bf16
+  auto commit = [&](int hb, const float (&src)[2][NCH]) {       // registers -> LDS halo buffer as NHWC8 bf16
     char* const hbuf = smem + hb * HALO_B;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       if (u == 1 && hp1 >= HP) continue;
       bf16x8 v;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (bf16_t)pre[u][e];
+      for (int e = 0; e < 8; ++e) v[e] = e < NCH ? (bf16_t)src[u][e < NCH ? e : 0] : (bf16_t)0.f;
       *reinterpret_cast<bf16x8*>(hbuf + (u ? hp1 : hp0) * 16) = v;
     }
   };
 
   char* const stg = smem + 2 * HALO_B + wave * (TM * SP);
-  fetch(0);
-  for (int t = 0; t < n_t; ++t) {
-    commit(t & 1);
+#pragma unroll
+  for (int t = 0; t < TPB; ++t)
+    if (t < n_t) fetch(t, pre[t]);
+#pragma unroll
+  for (int t = 0; t < TPB; ++t) {
+    if (t >= n_t) break;                   // (uniform)
+    commit(t & 1, pre[t]);
     wait_lds();                            // LDS-only barrier: the previous tile's stores stay in flight
     __builtin_amdgcn_s_barrier();          // halo t visible; (also: everyone is past the reads of halo t-2's buffer)
-    if (t + 1 < n_t) fetch(t + 1);         // global loads fly during the MFMAs and the stores below
     const char* const hbuf = smem + (t & 1) * HALO_B;
     const int x0 = (tx0 + t) * 16;
     f32x16 acc[2];

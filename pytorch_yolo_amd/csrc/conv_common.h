@@ -27,6 +27,11 @@ struct HeadDecodeArgs {
   int na, no, io_rows_total, io_row_offset;
   float stride;
   float anchor_w[4], anchor_h[4];   // anchors_px / stride (yolo_layer.py:109)
+  // filter mode (yolo_head_decode_filter_fwd; io == nullptr): the epilogue runs the NMS row filter on its own decoded rows and
+  // leaves a key per row + the survivors' records in the compact NMS workspace (nms_common.h) instead of storing io
+  float* rec;                        // [bs][io_rows_total][8]: x, y, w, h, class score of a surviving row, at its io row
+  unsigned long long* row_keys;      // [bs][io_rows_total]: the row's sort key if it survives, ~0 otherwise
+  float conf_thres, min_wh;
 };
 
 struct ConvArgs {

@@ -17,6 +17,7 @@
 // K tail, M tail) costs nothing: those lanes get a voffset beyond the descriptor's num_records and the
 // hardware writes zeros.  NS-stage LDS ring, counted vmcnt, one raw s_barrier per K step.
 #include "conv_common.h"
+#include "nms_common.h"
 #include <stdlib.h>
 
 using namespace yolo_conv;
@@ -434,14 +435,15 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NP)) void conv_igemm_bf16
       for (int i = 0; i < PPW && m < a.M; ++i, ++m) {
         const float* const srow = stg + (wave * PPW + i) * DP;
         float* const pimg = h.p ? h.p + ((long)b * h.na * hw_out + cell) * h.no : nullptr;
-        float* const iimg = h.io + ((long)b * h.io_rows_total + cell) * h.no;
+        float* const iimg = h.io ? h.io + ((long)b * h.io_rows_total + cell) * h.no : nullptr;
 #pragma unroll
         for (int j = 0; j < CJ; ++j) {
           if (c_k[j] < 0) continue;
           const float r = srow[lane + 64 * j];
           const float v = yolo_decode_elem<false>(r, c_k[j], gx, gy, c_anchor[j], h.stride, h.no - 5);
           if (pimg) pimg[c_poff[j]] = r;
-          iimg[c_ioff[j]] = v;
+          if (iimg) iimg[c_ioff[j]] = v;
+          else const_cast<float*>(srow)[lane + 64 * j] = v;   // filter mode: the decoded row stays in LDS for the scan below
         }
         ++cell;
         if (++gx == d.wo) {
@@ -450,6 +452,80 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NP)) void conv_igemm_bf16
             gy = 0;
             cell = 0;
             ++b;
+          }
+        }
+      }
+    }
+    if (!h.io) {
+      // ---- filter mode: the row filter of non_max_suppression (reference utils/utils.py:212-218; csrc/nms.hip nms_filter_kernel, whose
+      // arithmetic this repeats operation for operation on the SAME decoded values) over the wave's own PPW x na rows, straight from
+      // LDS.  Two lanes per row scan half of the classes each in order and are merged in order: first maximum wins, the first NaN
+      // poisons (torch.max semantics).  Every row leaves its key (class | ~conf | io row; ~0 if it does not survive) at its place in
+      // `row_keys`, a survivor also its record (x, y, w, h, class score) in `rec`.  io itself is never stored.
+      using namespace yolo_nms;
+      __builtin_amdgcn_wave_barrier();
+      wait_lds();                                       // this wave's decoded rows are in LDS (nobody else touches them)
+      const int nc = h.no - 5, half = (nc + 1) >> 1;
+      const int m_w0 = m0 + wave * PPW, rows_w = PPW * h.na;
+      for (int base = 0; base < rows_w; base += 32) {
+        const int rl = base + (lane >> 1), seg = lane & 1;
+        const int pi = rl / h.na, an = rl - pi * h.na;
+        const int mm = m_w0 + pi;
+        const bool live = rl < rows_w && mm < a.M;
+        const float* const row = stg + (wave * PPW + (live ? pi : 0)) * DP + (live ? an : 0) * h.no;
+        const int k0 = seg * half, k1 = min(nc, k0 + half);
+        // A row with a non-finite class score is dropped whatever its maximum is (utils.py:218), so the scan needs the NaN rules of
+        // torch.max only where they cannot matter: it keeps the first maximum (strict >) and the largest |bits| of the classes seen -
+        // all of them finite <=> that is below the exponent mask.  3 + 2 VALU instructions per class, no branches.
+        bool have = k0 < k1;
+        float best = have ? row[5 + k0] : 0.f;
+        int arg = k0;
+        uint32_t amax = have ? (__float_as_uint(best) & 0x7fffffffu) : 0u;
+        auto take = [&](float v, int k) {
+          amax = max(amax, __float_as_uint(v) & 0x7fffffffu);
+          const bool t = v > best;
+          best = t ? v : best;
+          arg = t ? k : arg;
+        };
+        int k = k0 + 1;
+        for (; k + 8 <= k1; k += 8) {                    // eight LDS reads in flight, then the compares in class order
+          float v8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v8[e] = row[5 + k + e];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) take(v8[e], k + e);
+        }
+        for (; k < k1; ++k) take(row[5 + k], k);
+        {                                               // the two halves in class order: the right one wins only with a larger maximum
+          const float ob = __shfl_xor(best, 1);
+          const int oa = __shfl_xor(arg, 1);
+          const bool oh = __shfl_xor((int)have, 1) != 0;
+          amax = max(amax, (uint32_t)__shfl_xor((int)amax, 1));
+          const bool other_is_right = seg == 0;
+          const float lb = other_is_right ? best : ob, rb = other_is_right ? ob : best;
+          const int la = other_is_right ? arg : oa, ra = other_is_right ? oa : arg;
+          const bool lh = other_is_right ? have : oh, rh = other_is_right ? oh : have;
+          const bool take_r = rh & (!lh | (rb > lb));
+          best = take_r ? rb : lb;
+          arg = take_r ? ra : la;
+        }
+        bool all_finite = amax < 0x7f800000u;
+        bool keep = false;
+        float conf = 0.f;
+        const int bimg = live ? mm / hw_out : 0;
+        const int iorow = h.io_row_offset + an * hw_out + (mm - bimg * hw_out);
+        if (live && seg == 0) {
+          conf = row[4] * best;                                                        // utils.py:213
+          const float bw = row[2], bh = row[3];
+          all_finite = all_finite && finite_f(row[0]) && finite_f(row[1]) && finite_f(bw) && finite_f(bh) && finite_f(conf);
+          keep = (conf > h.conf_thres) && (bw > h.min_wh) && (bh > h.min_wh) && all_finite;  // :216-218
+        }
+        if (live && seg == 0) {                           // one key per row (no atomics): nms_merge compacts them
+          h.row_keys[(long)bimg * h.io_rows_total + iorow] = keep ? make_key(arg, conf, iorow) : ~0ull;
+          if (keep) {
+            float* const rp = h.rec + ((long)bimg * h.io_rows_total + iorow) * kRecFloats;
+            *reinterpret_cast<f32x4*>(rp) = f32x4{row[0], row[1], row[2], row[3]};
+            rp[4] = best;
           }
         }
       }
@@ -982,7 +1058,48 @@ extern "C" int yolo_head_decode_fwd(const void* x, const void* w_packed, const f
     h.anchor_w[i] = i < na ? anchors_px[2 * i] / stride_px : 0.f;
     h.anchor_h[i] = i < na ? anchors_px[2 * i + 1] / stride_px : 0.f;
   }
+  h.rec = nullptr, h.row_keys = nullptr, h.conf_thres = 0.f, h.min_wh = 0.f;
   YoloConvDesc dd = d;              // the output view is unused: give the shared checks a consistent one
+  dd.out_dtype = YOLO_DT_F32;
+  dd.out_c_total = (d.cout + 3) & ~3;
+  dd.out_c_offset = 0;
+  return conv2d_launch_ex(x, w_packed, bias, nullptr, nullptr, nullptr, &dd, &h, (hipStream_t)s);
+}
+
+// Head conv + decode + the NMS row filter in one launch: io is never written (include/yolo_hip.h, the compact NMS form).
+extern "C" int yolo_head_decode_filter_fwd(const void* x, const void* w_packed, const float* bias, const YoloConvDesc* dp,
+                                           const float* anchors_px, int na, int nc, float stride_px, int io_rows_total,
+                                           int io_row_offset, float conf_thres, float min_wh, void* workspace,
+                                           size_t workspace_bytes, float* p, yolo_stream_t s) {
+  YOLO_REQUIRE(dp && anchors_px && workspace, "head_decode_filter: null pointer");
+  const YoloConvDesc& d = *dp;
+  YOLO_REQUIRE(yolo_head_decode_supported(d.cout, na, nc), "head_decode_filter: cout %d != na*(5+nc) = %d*%d or out of range", d.cout,
+               na, 5 + nc);
+  YOLO_REQUIRE(d.stride == 1 && !d.upsample2x, "head_decode_filter: stride-1 head convs only");
+  YOLO_REQUIRE(io_row_offset >= 0 && io_row_offset + na * d.ho * d.wo <= io_rows_total, "head_decode_filter: rows out of range");
+  YOLO_REQUIRE(io_rows_total < (1 << 20), "head_decode_filter: rows %d >= 2^20 unsupported", io_rows_total);
+  YOLO_REQUIRE(stride_px > 0.f, "head_decode_filter: bad stride");
+  if (workspace_bytes < yolo_nms_compact_workspace_bytes(d.n, io_rows_total, nc))
+    return yolo_set_error(YOLO_E_WORKSPACE, "head_decode_filter: workspace %zu < %zu bytes", workspace_bytes,
+                          yolo_nms_compact_workspace_bytes(d.n, io_rows_total, nc));
+  const yolo_nms::Workspace w = yolo_nms::carve(workspace, d.n, io_rows_total, nc, true);
+  HeadDecodeArgs h;
+  h.io = nullptr;
+  h.p = p;
+  h.na = na;
+  h.no = nc + 5;
+  h.io_rows_total = io_rows_total;
+  h.io_row_offset = io_row_offset;
+  h.stride = stride_px;
+  for (int i = 0; i < 4; ++i) {
+    h.anchor_w[i] = i < na ? anchors_px[2 * i] / stride_px : 0.f;
+    h.anchor_h[i] = i < na ? anchors_px[2 * i + 1] / stride_px : 0.f;
+  }
+  h.rec = w.rec;
+  h.row_keys = w.row_keys;
+  h.conf_thres = conf_thres;
+  h.min_wh = min_wh;
+  YoloConvDesc dd = d;
   dd.out_dtype = YOLO_DT_F32;
   dd.out_c_total = (d.cout + 3) & ~3;
   dd.out_c_offset = 0;

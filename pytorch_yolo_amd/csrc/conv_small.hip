@@ -11,6 +11,9 @@
 
 using namespace yolo_conv;
 
+#ifndef YOLO_SMALL_WGS
+#define YOLO_SMALL_WGS 2         // resident workgroups per CU the register budget is cut for (and the persistent grid is sized for)
+#endif
 #ifndef YOLO_SMALL_PAD32
 #define YOLO_SMALL_PAD32 16      // extra bytes per 64-byte halo pixel in LDS
 #endif
@@ -19,7 +22,7 @@ namespace {
 
 // CIN 16 or 32 (NHWC bf16), COUT 32 or 64: 4 waves per 32 output channels (wave = (64-pixel group, cout half)).
 template <int CIN, int COUT, bool POOL>
-__global__ __launch_bounds__(COUT * 8) void conv3x3_small_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(COUT * 8, (COUT == 32 ? YOLO_SMALL_WGS : (YOLO_SMALL_WGS + 1) / 2)) void conv3x3_small_kernel(const ConvArgs a) {
   constexpr int NWV = COUT / 8, NT = NWV * 64;
   constexpr int HW2 = 18, HP = 18 * 18, TM = 64, KS = 9 * CIN / 16, CPP = CIN / 8;
   constexpr int PS = CIN * 2 + (CIN == 32 ? YOLO_SMALL_PAD32 : 0);  // halo pixel pitch (measured: + 16 B helps 64-byte pixels only)
@@ -293,7 +296,8 @@ int launch_small_p(const ConvArgs& a, hipStream_t s) {
   const YoloConvDesc& d = a.d;
   const long n_tiles = (long)d.n * ((d.h + 15) / 16) * ((d.w + 15) / 16);
   if (n_tiles > 0x7fffffffL) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv grid too large");
-  const long grid = n_tiles < 512 ? n_tiles : 512;       // persistent: two workgroups per CU
+  constexpr long kGrid = 256L * (COUT == 32 ? YOLO_SMALL_WGS : (YOLO_SMALL_WGS + 1) / 2 * 1);
+  const long grid = n_tiles < kGrid ? n_tiles : kGrid;   // persistent: YOLO_SMALL_WGS workgroups of 4 waves (half as many of 8) per CU
   hipLaunchKernelGGL((conv3x3_small_kernel<CIN, COUT, POOL>), dim3((unsigned)grid), dim3(COUT * 8), lds, s, a);
   return yolo_check_launch("yolo_conv3x3_pool_fwd");
 }

@@ -15,35 +15,14 @@
 //   nms_merge  : one 1024-thread workgroup per image: bitonic sort of the keys (LDS up to 8192 keys,
 //                global workspace beyond), class segments, one wave per class runs the sequential
 //                MERGE over its first max_per_class rows with ballot masks, final sort by conf.
-#include "common.h"
+#include "nms_common.h"
 
 namespace {
 
-typedef unsigned long long u64;
+using namespace yolo_nms;
 
-constexpr int kLdsKeys = 8192;     // keys sorted in LDS; more survivors -> sort in the global workspace
-constexpr int kMaxClasses = 1024;
-constexpr int kMaxPerClassCap = 128;  // 2 candidates per lane
 constexpr int kMergeThreads = 1024;
 constexpr int kFilterRows = 64;
-
-// monotone float -> uint map (ascending), valid for every non-NaN float
-__device__ __forceinline__ uint32_t f32_sortable(float f) {
-  const uint32_t u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float f32_unsortable(uint32_t s) {
-  return __uint_as_float((s & 0x80000000u) ? (s & 0x7fffffffu) : ~s);
-}
-// key = class:12 | ~sortable(conf):32 | row:20   -> ascending key == (class asc, conf desc, row asc)
-__device__ __forceinline__ u64 make_key(int cls, float conf, int row) {
-  return ((u64)cls << 52) | ((u64)(~f32_sortable(conf)) << 20) | (u64)row;
-}
-__device__ __forceinline__ int key_class(u64 k) { return (int)(k >> 52); }
-__device__ __forceinline__ float key_conf(u64 k) { return f32_unsortable(~(uint32_t)(k >> 20)); }
-__device__ __forceinline__ int key_row(u64 k) { return (int)(k & 0xfffffu); }
-
-__device__ __forceinline__ bool finite_f(float v) { return (__float_as_uint(v) & 0x7f800000u) != 0x7f800000u; }
 
 __device__ __forceinline__ float readlane_f(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
@@ -242,6 +221,8 @@ struct MergeArgs {
   int* out_idx;       // [bs][cap]
   int* out_count;     // [bs]
   int rows, no, nc, max_per_class, cap, stage_cap;
+  int cc_index;       // index of the class score inside a row: -1 = 5 + class (an io row), >= 0 = fixed (compact records: 4)
+  const u64* row_keys;  // compact form: [bs][rows] one key per io row (~0: not a survivor), compacted into `keys` here; else null
   long key_pitch;     // keys per image row of the workspace (power of two >= rows)
   float nms_thres;
 };
@@ -254,7 +235,29 @@ __global__ __launch_bounds__(kMergeThreads) void nms_merge_kernel(const MergeArg
   __shared__ int s_list[kMaxClasses];
 
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-  const int n = min(a.counts[b], a.rows);
+  u64* const gkeys0 = a.keys + (long)b * a.key_pitch;
+  if (a.row_keys) {
+    // compact form: gather the survivors' keys (order is free: they are sorted below) - one LDS atomic per wave and pass
+    if (tid == 0) s_nout = 0;
+    __syncthreads();
+    const u64* const rk = a.row_keys + (long)b * a.rows;
+    for (int i0 = 0; i0 < a.rows; i0 += kMergeThreads) {
+      const int i = i0 + tid;
+      const u64 k = i < a.rows ? rk[i] : ~0ull;
+      const bool sv = k != ~0ull;
+      const u64 mask = __ballot(sv);
+      if (mask) {
+        const int leader = __builtin_ctzll(mask);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&s_nout, __builtin_popcountll(mask));
+        base = __builtin_amdgcn_readlane(base, leader);
+        if (sv) gkeys0[base + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = k;
+      }
+    }
+    __syncthreads();                                   // (block-wide: the gathered keys are visible to every thread)
+  }
+  const int n = a.row_keys ? s_nout : min(a.counts[b], a.rows);
+  __syncthreads();                                     // (s_nout is reset below)
   if (n == 0) {
     if (tid == 0) a.out_count[b] = 0;
     return;
@@ -326,7 +329,7 @@ __global__ __launch_bounds__(kMergeThreads) void nms_merge_kernel(const MergeArg
 #pragma unroll
         for (int e = 0; e < 4; ++e) wp[h][e] = ws[h] * bx[h][e];
         my_row[h] = r;
-        my_cconf[h] = pr[5 + c];
+        my_cconf[h] = pr[a.cc_index >= 0 ? a.cc_index : 5 + c];
       }
     }
 
@@ -476,39 +479,57 @@ __global__ __launch_bounds__(256) void pack_detections_kernel(const float* __res
     for (int i = threadIdx.x; i < n; i += 256) packed_idx[off + i] = idx[(long)b * cap + i];
 }
 
-inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
-inline size_t pow2_at_least(size_t v) {
-  size_t p = 1;
-  while (p < v) p <<= 1;
-  return p;
-}
-inline int stage_cap_for(int rows, int nc, int max_per_class) {
-  long c = (long)nc * max_per_class;
-  if (c > rows) c = rows;
-  if (c > kLdsKeys) c = kLdsKeys;
-  return (int)c;
-}
-
 }  // namespace
 
 extern "C" size_t yolo_nms_workspace_bytes(int bs, int rows, int nc) {
   if (bs <= 0 || rows <= 0 || nc <= 0) return 0;
-  const size_t counts = align256((size_t)bs * 4);
-  const size_t keys = align256((size_t)bs * pow2_at_least((size_t)rows) * 8);
-  const size_t stage = align256((size_t)bs * stage_cap_for(rows, nc, kMaxPerClassCap) * 8 * 4);
-  return counts + keys + stage;
+  return carve(nullptr, bs, rows, nc, false).bytes;
+}
+extern "C" size_t yolo_nms_compact_workspace_bytes(int bs, int rows, int nc) {
+  if (bs <= 0 || rows <= 0 || nc <= 0) return 0;
+  return carve(nullptr, bs, rows, nc, true).bytes;
 }
 
-extern "C" int yolo_nms_merge(float* pred, int bs, int rows, int nc, float conf_thres, float nms_thres, float min_wh,
-                              int max_per_class, int mutate_conf, float* out_dets, int32_t* out_idx, int32_t* out_count,
-                              int cap, void* workspace, size_t workspace_bytes, yolo_stream_t s) {
-  YOLO_REQUIRE(pred && out_dets && out_idx && out_count && workspace, "nms: null pointer");
+static int nms_check(int bs, int rows, int nc, float nms_thres, int max_per_class, int cap) {
   YOLO_REQUIRE(bs > 0 && rows > 0 && nc > 0 && cap > 0, "nms: bad sizes");
   YOLO_REQUIRE(nc <= kMaxClasses, "nms: n_class %d > %d unsupported", nc, kMaxClasses);
   YOLO_REQUIRE(rows < (1 << 20), "nms: rows %d >= 2^20 unsupported", rows);
   YOLO_REQUIRE(max_per_class >= 1 && max_per_class <= kMaxPerClassCap, "nms: max_per_class %d not in [1,%d]", max_per_class,
                kMaxPerClassCap);
   YOLO_REQUIRE(nms_thres < 1.f, "nms: nms_thres must be < 1 (the reference never terminates otherwise)");
+  return 0;
+}
+
+static int launch_merge(const float* rows_base, int row_floats, int cc_index, const Workspace& w, int bs, int rows, int nc,
+                        float nms_thres, int max_per_class, float* out_dets, int32_t* out_idx, int32_t* out_count, int cap,
+                        hipStream_t st) {
+  MergeArgs a;
+  a.pred = rows_base;
+  a.keys = w.keys;
+  a.counts = w.counts;
+  a.stage = w.stage;
+  a.out_dets = out_dets;
+  a.out_idx = out_idx;
+  a.out_count = out_count;
+  a.rows = rows;
+  a.key_pitch = w.key_pitch;
+  a.no = row_floats;
+  a.nc = nc;
+  a.max_per_class = max_per_class;
+  a.cap = cap;
+  a.stage_cap = w.stage_cap;
+  a.cc_index = cc_index;
+  a.row_keys = w.row_keys;
+  a.nms_thres = nms_thres;
+  hipLaunchKernelGGL(nms_merge_kernel, dim3((unsigned)bs), dim3(kMergeThreads), 0, st, a);
+  return yolo_check_launch("yolo_nms_merge(merge)");
+}
+
+extern "C" int yolo_nms_merge(float* pred, int bs, int rows, int nc, float conf_thres, float nms_thres, float min_wh,
+                              int max_per_class, int mutate_conf, float* out_dets, int32_t* out_idx, int32_t* out_count,
+                              int cap, void* workspace, size_t workspace_bytes, yolo_stream_t s) {
+  YOLO_REQUIRE(pred && out_dets && out_idx && out_count && workspace, "nms: null pointer");
+  if (int rc = nms_check(bs, rows, nc, nms_thres, max_per_class, cap)) return rc;
   const int no = nc + 5;
   const size_t tile_bytes = (size_t)kFilterRows * no * 4;
   YOLO_REQUIRE(tile_bytes <= 64 * 1024, "nms: row of %d floats too wide", no);
@@ -516,39 +537,28 @@ extern "C" int yolo_nms_merge(float* pred, int bs, int rows, int nc, float conf_
     return yolo_set_error(YOLO_E_WORKSPACE, "nms: workspace %zu < %zu bytes", workspace_bytes,
                           yolo_nms_workspace_bytes(bs, rows, nc));
   hipStream_t st = (hipStream_t)s;
-  char* ws = (char*)workspace;
-  int* counts = (int*)ws;
-  ws += align256((size_t)bs * 4);
-  const size_t row_keys = pow2_at_least((size_t)rows);
-  u64* keys = (u64*)ws;
-  ws += align256((size_t)bs * row_keys * 8);
-  float* stage = (float*)ws;
-
-  hipError_t e = hipMemsetAsync(counts, 0, align256((size_t)bs * 4), st);
+  const Workspace w = carve(workspace, bs, rows, nc, false);
+  hipError_t e = hipMemsetAsync(w.counts, 0, align256((size_t)bs * 4), st);
   if (e != hipSuccess) return yolo_set_error((int)e, "nms: memset: %s", hipGetErrorString(e));
   dim3 fgrid((unsigned)((rows + kFilterRows - 1) / kFilterRows), (unsigned)bs);
   hipLaunchKernelGGL(nms_filter_kernel, fgrid, dim3(256), tile_bytes, st, pred, rows, no, conf_thres, min_wh, mutate_conf,
-                     keys, (long)row_keys, counts);
-  int rc = yolo_check_launch("yolo_nms_merge(filter)");
-  if (rc) return rc;
-  MergeArgs a;
-  a.pred = pred;
-  a.keys = keys;
-  a.counts = counts;
-  a.stage = stage;
-  a.out_dets = out_dets;
-  a.out_idx = out_idx;
-  a.out_count = out_count;
-  a.rows = rows;
-  a.key_pitch = (long)row_keys;
-  a.no = no;
-  a.nc = nc;
-  a.max_per_class = max_per_class;
-  a.cap = cap;
-  a.stage_cap = stage_cap_for(rows, nc, kMaxPerClassCap);
-  a.nms_thres = nms_thres;
-  hipLaunchKernelGGL(nms_merge_kernel, dim3((unsigned)bs), dim3(kMergeThreads), 0, st, a);
-  return yolo_check_launch("yolo_nms_merge(merge)");
+                     w.keys, w.key_pitch, w.counts);
+  if (int rc = yolo_check_launch("yolo_nms_merge(filter)")) return rc;
+  return launch_merge(pred, no, -1, w, bs, rows, nc, nms_thres, max_per_class, out_dets, out_idx, out_count, cap, st);
+}
+
+// ---- the compact form (include/yolo_hip.h): the head convs' epilogues filter their own rows (yolo_head_decode_filter_fwd appends keys
+// and writes the survivors' records), so io is never written and never read back: head launches -> merge
+extern "C" int yolo_nms_merge_compact(void* workspace, size_t workspace_bytes, int bs, int rows, int nc, float nms_thres,
+                                      int max_per_class, float* out_dets, int32_t* out_idx, int32_t* out_count, int cap,
+                                      yolo_stream_t s) {
+  YOLO_REQUIRE(workspace && out_dets && out_idx && out_count, "nms_merge_compact: null pointer");
+  if (int rc = nms_check(bs, rows, nc, nms_thres, max_per_class, cap)) return rc;
+  if (workspace_bytes < yolo_nms_compact_workspace_bytes(bs, rows, nc))
+    return yolo_set_error(YOLO_E_WORKSPACE, "nms_compact: workspace %zu < %zu bytes", workspace_bytes,
+                          yolo_nms_compact_workspace_bytes(bs, rows, nc));
+  const Workspace w = carve(workspace, bs, rows, nc, true);
+  return launch_merge(w.rec, kRecFloats, 4, w, bs, rows, nc, nms_thres, max_per_class, out_dets, out_idx, out_count, cap, (hipStream_t)s);
 }
 
 

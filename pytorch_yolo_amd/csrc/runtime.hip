@@ -87,6 +87,12 @@ extern "C" int yolo_run_ops(const YoloOp* ops, int n_ops, yolo_stream_t s) {
         rc = yolo_stem_fwd((const float*)o.x, d.res_c_total, o.w_pre, o.bias_pre, o.kpad_pre, o.w, o.bias, o.y, &d, s);
         break;
       case YOLO_OP_HEAD_DECODE:
+        if (!o.y && o.workspace) {
+          rc = yolo_head_decode_filter_fwd(o.x, o.w, o.bias, &d, o.head_anchors_px, o.head_na, o.head_nc, o.head_stride_px, o.io_rows_total,
+                                           o.io_row_offset, o.head_filter_conf, o.head_filter_min_wh, o.workspace, o.ws_bytes,
+                                           (float*)o.y_aux, s);
+          break;
+        }
         rc = yolo_head_decode_fwd(o.x, o.w, o.bias, &d, o.head_anchors_px, o.head_na, o.head_nc, o.head_stride_px, (float*)o.y,
                                   o.io_rows_total, o.io_row_offset, (float*)o.y_aux, s);
         break;
@@ -158,14 +164,17 @@ extern "C" int yolo_pipeline_step(const YoloPipeStep* st) {
   int rc = yolo_run_ops(st->ops, st->k_io, st->stream);
   if (rc) return rc;
   if (st->wait_io) YOLO_HIP_TRY(hipStreamWaitEvent(s, (hipEvent_t)st->wait_io, 0), "hipStreamWaitEvent(io)");
+  const bool compact = st->io == nullptr;
   rc = yolo_run_ops(st->ops + st->k_io, st->n_ops - st->k_io, st->stream);
   if (rc) return rc;
   if (ns != s) {
     YOLO_HIP_TRY(hipEventRecord((hipEvent_t)st->heads_done, s), "hipEventRecord(heads)");
     YOLO_HIP_TRY(hipStreamWaitEvent(ns, (hipEvent_t)st->heads_done, 0), "hipStreamWaitEvent(heads)");
   }
-  rc = yolo_nms_merge(st->io, st->bs, st->rows, st->nc, st->conf_thres, st->nms_thres, st->min_wh, st->max_per_class, 0, st->out_dets,
-                      st->out_idx, st->out_count, st->cap, st->workspace, st->workspace_bytes, st->nms_stream);
+  rc = compact ? yolo_nms_merge_compact(st->workspace, st->workspace_bytes, st->bs, st->rows, st->nc, st->nms_thres, st->max_per_class,
+                                        st->out_dets, st->out_idx, st->out_count, st->cap, st->nms_stream)
+               : yolo_nms_merge(st->io, st->bs, st->rows, st->nc, st->conf_thres, st->nms_thres, st->min_wh, st->max_per_class, 0,
+                                st->out_dets, st->out_idx, st->out_count, st->cap, st->workspace, st->workspace_bytes, st->nms_stream);
   if (rc) return rc;
   if (st->count_host)
     YOLO_HIP_TRY(hipMemcpyAsync(st->count_host, st->out_count, (size_t)st->bs * 4, hipMemcpyDeviceToHost, ns), "hipMemcpyAsync(count)");

@@ -848,12 +848,14 @@ class Plan:
         else:
             K.pack_input(x, self.input_buffer)
 
-    def _launch(self, x: torch.Tensor, io: torch.Tensor, ps, timing=None, before_io=None):
+    def _launch(self, x: torch.Tensor, io: torch.Tensor, ps, timing=None, before_io=None, compact=None):
         """pack -> layer list -> decodes on the current stream.  ``timing`` = (start, end) torch events
         recorded around the layer list (bench.py's roofline measurement).  ``before_io()`` is called right before the first
-        launch that writes ``io`` (a pipelined caller makes the stream wait there for the previous batch's NMS, which reads it)."""
+        launch that writes ``io`` (a pipelined caller makes the stream wait there for the previous batch's NMS, which reads it).
+        ``compact`` = (workspace, conf_thres, min_wh): the heads filter their rows into the compact NMS workspace instead of
+        storing ``io`` (which may be None then); ``before_io`` then guards the workspace the same way."""
         self.feed(x)
-        self._bind_outputs(io, ps)
+        self._bind_outputs(io, ps, compact)
         if timing is not None:
             timing[0].record()
         fused = [hd["op"] for hd in self.heads if hd["op"] is not None]
@@ -871,14 +873,41 @@ class Plan:
             timing[1].record()
         self._decode_unfused(io, ps)
 
-    def _bind_outputs(self, io, ps):
-        """Heads that decode in their conv epilogue write io / p themselves: patch this call's buffers into their ops."""
+    @property
+    def compact_ok(self) -> bool:
+        """Every head decodes in its conv epilogue (bf16 mode): detect() can take the compact NMS form (no io)."""
+        return not self.f32 and all(hd["op"] is not None for hd in self.heads)
+
+    def compact_workspace(self) -> torch.Tensor:
+        """This plan's compact NMS workspace (survivor counts, keys, staging, records: yolo_nms_compact_workspace_bytes), made once."""
+        ws = self.__dict__.get("_compact_ws")
+        if ws is None:
+            ws = self._compact_ws = torch.empty(K.nms_compact_workspace_bytes(self.rec.input.n, self.rows_total, self.n_class),
+                                                dtype=torch.uint8, device=self.device)
+        return ws
+
+    def _bind_outputs(self, io, ps, compact=None):
+        """Heads that decode in their conv epilogue write io / p themselves: patch this call's buffers into their ops.
+        ``compact`` = (workspace, conf_thres, min_wh): they filter into the compact NMS workspace instead and store no io."""
+        if compact is not None:
+            if not self.compact_ok:
+                raise RuntimeError("the compact NMS form needs every head to decode in its conv epilogue")
+            ws, conf, min_wh = compact
+            for hd, p in zip(self.heads, ps):
+                op = self.op_array[hd["op"]]
+                op.y, op.y_aux = None, (p.data_ptr() if p is not None else None)
+                op.workspace, op.ws_bytes = ws.data_ptr(), ws.numel()
+                op.head_filter_conf, op.head_filter_min_wh = float(conf), float(min_wh)
+            self._bound = (ws.data_ptr(), float(conf), tuple(None if p is None else p.data_ptr() for p in ps))
+            return
         if io.shape[1] != self.rows_total or not io.is_contiguous():
             raise RuntimeError("io must be a contiguous [bs, rows_total, 5+nc] tensor")
         for hd, p in zip(self.heads, ps):
             if hd["op"] is not None:
                 op = self.op_array[hd["op"]]
                 op.y, op.y_aux = io.data_ptr(), (p.data_ptr() if p is not None else None)
+                op.workspace, op.ws_bytes = None, 0
+        self._bound = (io.data_ptr(), None, tuple(None if p is None else p.data_ptr() for p in ps))
 
     def _decode_unfused(self, io, ps):
         for hd, p in zip(self.heads, ps):
@@ -886,14 +915,20 @@ class Plan:
                 K.decode(hd["sym"].buf.tensor, hd["anchors"], self.n_class, hd["stride"], io, hd["row"], p)
 
     def launch_detect(self, x, io, ps, nms_out, conf_thres, nms_thres, timing=None, join=True, after_nms=None, whole_batch=False,
-                      wait_for=None):
-        """forward + decode + MERGE-NMS into caller-provided buffers; no host sync.
+                      wait_for=None, compact=False):
+        """forward + decode + MERGE-NMS into caller-provided buffers; no host sync.  ``compact=True``: the compact NMS form
+        (``io`` is not written and may be None; include/yolo_hip.h yolo_head_decode_filter_fwd) where the plan allows it.
         nms_out = (dets [bs,cap,7] f32, idx [bs,cap] i32, count [bs] i32).  ``timing``: one (start, end)
         event pair per stream, recorded around the conv launch list.  ``after_nms(i, lo, hi)`` is called in
         the context of stream i right after the NMS launch of images [lo, hi) (see distributed.PipelinedGather)."""
-        from .utils.utils import nms_launch
-        self._launch(x, io, ps, timing=timing[0] if timing else None)
-        nms_launch(io, conf_thres, nms_thres, nms_out, slot=0)
+        from .utils.utils import MAX_PER_CLASS, MIN_WH, nms_launch
+        if compact and self.compact_ok:
+            ws = self.compact_workspace()
+            self._launch(x, None, ps, timing=timing[0] if timing else None, compact=(ws, conf_thres, MIN_WH))
+            K.nms_merge_compact(ws, x.shape[0], self.rows_total, self.n_class, nms_thres, *nms_out, max_per_class=MAX_PER_CLASS)
+        else:
+            self._launch(x, io, ps, timing=timing[0] if timing else None)
+            nms_launch(io, conf_thres, nms_thres, nms_out, slot=0)
         if after_nms is not None:
             after_nms(0, 0, x.shape[0])
 
@@ -1159,8 +1194,11 @@ class StreamedPlan:
         return len(self.streams)
 
     def launch_detect(self, x, io, ps, nms_out, conf_thres, nms_thres, timing=None, join=True, after_nms=None, whole_batch=False,
-                      wait_for=None, cu_partition=False):
-        """``wait_for``: an event every pipeline of this call waits for before its first launch (pipelined calls do not wait for
+                      wait_for=None, cu_partition=False, compact=False):
+        """``compact=True``: the compact NMS form - the heads filter their own rows, ``io`` is neither written nor read and may be
+        None (include/yolo_hip.h yolo_head_decode_filter_fwd; +1.7 % on SPP-640 x 32 from the io store alone) - where the plans allow it.
+
+        ``wait_for``: an event every pipeline of this call waits for before its first launch (pipelined calls do not wait for
         the calling stream: pass the event that says ``x`` is ready when another stream produced it).
 
         ``cu_partition=True`` (whole-batch pipelines only): each pipeline launches on a stream that owns half of every XCD's CUs
@@ -1182,7 +1220,7 @@ class StreamedPlan:
         work nor for this one: successive calls then form S free-running pipelines (in-order per stream, so
         buffer reuse is safe) — the caller synchronises before reading results, and before a joined call on the same plan
         (the pipelines run on their own, CU-partitioned streams: ``pipe_streams``)."""
-        from .utils.utils import nms_launch
+        from .utils.utils import MAX_PER_CLASS, MIN_WH, nms_launch
         cur = torch.cuda.current_stream()
         whole = whole_batch and not join
         if whole:
@@ -1219,19 +1257,25 @@ class StreamedPlan:
             tm = (timing[0 if whole else i] if timing else None)
             if wait_for is not None:
                 st.wait_event(wait_for)
+            cmp_ = (pl.compact_workspace(), conf_thres, MIN_WH) if (compact and pl.compact_ok) else None
+            sub_io = None if cmp_ is not None else io[lo:hi]
             with torch.cuda.stream(st), _launch_cus(share):
                 if not side_nms:
-                    pl._launch(x[lo:hi], io[lo:hi], sub_ps, timing=tm)
+                    pl._launch(x[lo:hi], sub_io, sub_ps, timing=tm, compact=cmp_)
                 else:
                     prev = self._nms_done[i]
-                    pl._launch(x[lo:hi], io[lo:hi], sub_ps, timing=tm,
+                    pl._launch(x[lo:hi], sub_io, sub_ps, timing=tm, compact=cmp_,
                                before_io=(lambda prev=prev, st=st: st.wait_event(prev)) if prev is not None else None)
                     self._heads_done[i].record(st)
             nst = self._nms_streams[i % len(self._nms_streams)] if side_nms else st
             with torch.cuda.stream(nst):
                 if side_nms:
                     nst.wait_event(self._heads_done[i])
-                nms_launch(io[lo:hi], conf_thres, nms_thres, tuple(t[lo:hi] for t in nms_out), slot=i)
+                if cmp_ is not None:
+                    K.nms_merge_compact(cmp_[0], hi - lo, pl.rows_total, pl.n_class, nms_thres, *(t[lo:hi] for t in nms_out),
+                                        max_per_class=MAX_PER_CLASS)
+                else:
+                    nms_launch(io[lo:hi], conf_thres, nms_thres, tuple(t[lo:hi] for t in nms_out), slot=i)
                 if after_nms is not None:
                     after_nms(i, lo, hi)
                 if side_nms:
@@ -1253,9 +1297,10 @@ class StreamedPlan:
 
     # -- the one-call pipeline step (yolo_pipeline_step): what detect_stream() launches per batch ------------------------------
     def fast_pipeline(self, slot: int, io, out, conf_thres, nms_thres):
-        """A ``FastStep`` for ring slot ``slot`` (buffers ``io``, ``out`` = (dets, idx, count)): the whole-batch launch list of
-        pipeline ``slot % S`` + NMS as ONE FFI call per batch, or None when this plan cannot take it (a head that decodes in a
-        launch of its own, an input the first layer does not read itself: then ``launch_detect`` does the same work)."""
+        """A ``FastStep`` for ring slot ``slot`` (``out`` = (dets, idx, count); ``io`` = None: the compact NMS form, no io at all;
+        a tensor: the heads store io there and the plain NMS reads it): the whole-batch launch list of pipeline ``slot % S`` + NMS
+        as ONE FFI call per batch, or None when this plan cannot take it (a head that decodes in a launch of its own, an input the
+        first layer does not read itself: then ``launch_detect`` does the same work)."""
         k = slot % len(self.streams)
         if self._full is None:
             with torch.cuda.device(self.device):
@@ -1275,12 +1320,11 @@ class StreamedPlan:
         if fs is None:
             from .utils.utils import nms_capacity
             with torch.cuda.device(self.device):
-                io, _ = self.new_outputs(want_p=False)
                 cap = nms_capacity(self.rows_total, self.n_class)
                 out = (torch.empty((self.bs, cap, 7), dtype=torch.float32, device=self.device),
                        torch.empty((self.bs, cap), dtype=torch.int32, device=self.device),
                        torch.empty((self.bs,), dtype=torch.int32, device=self.device))
-                fs = self.fast_pipeline(0, io, out, conf_thres, nms_thres) or False
+                fs = self.fast_pipeline(0, None, out, conf_thres, nms_thres) or False      # (compact NMS form: no io)
             self._detect_fast = fs
         if fs is False:
             return None
@@ -1312,8 +1356,10 @@ class FastStep:
         from ._lib import YoloPipeStep
         from .utils.utils import MAX_PER_CLASS, MIN_WH
         self.sp, self.k, self.pl, self.io, self.out = sp, k, pl, io, out
-        bs, rows, nc = io.shape[0], io.shape[1], io.shape[2] - 5
-        self.ws = torch.empty(K.nms_workspace_bytes(bs, rows, nc), dtype=torch.uint8, device=sp.device)
+        bs, rows, nc = sp.bs, pl.rows_total, pl.n_class
+        self.compact = (torch.empty(K.nms_compact_workspace_bytes(bs, rows, nc), dtype=torch.uint8, device=sp.device), conf_thres,
+                        MIN_WH) if io is None else None            # (a workspace per slot: two slots of a pipeline may be in flight)
+        self.ws = self.compact[0] if io is None else torch.empty(K.nms_workspace_bytes(bs, rows, nc), dtype=torch.uint8, device=sp.device)
         self.count_host = torch.empty(bs, dtype=torch.int32).pin_memory()
         self.count_np = self.count_host.numpy()
         self.ready, self.done = K.Event(), K.Event()
@@ -1325,7 +1371,7 @@ class FastStep:
         st.ops, st.n_ops, st.k_io = pl.op_array, pl.n_ops, min(fused)
         st.stream, st.nms_stream = sp.streams[k].cuda_stream, sp._nms_streams[k].cuda_stream
         st.wait_x, st.wait_io, st.heads_done, st.nms_done, st.done = self.ready.handle, None, heads_done.handle, nms_done.handle, self.done.handle
-        st.io, st.bs, st.rows, st.nc, st.max_per_class = io.data_ptr(), bs, rows, nc, MAX_PER_CLASS
+        st.io, st.bs, st.rows, st.nc, st.max_per_class = (None if io is None else io.data_ptr()), bs, rows, nc, MAX_PER_CLASS
         st.conf_thres, st.nms_thres, st.min_wh, st.cap = float(conf_thres), float(nms_thres), MIN_WH, out[0].shape[1]
         st.out_dets, st.out_idx, st.out_count = out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr()
         st.workspace, st.workspace_bytes, st.count_host = self.ws.data_ptr(), self.ws.numel(), self.count_host.data_ptr()
@@ -1341,9 +1387,15 @@ class FastStep:
         if x.dtype != torch.float32 or not x.is_contiguous() or tuple(x.shape[1:]) != self._x_shape or x.shape[0] != sp.bs:
             raise RuntimeError("input must be contiguous float32 NCHW of the planned shape")
         pl.op_array[0].x = x.data_ptr()
-        if pl.__dict__.get("_bound_io") != self.step.io:        # (the plan may have served launch_detect with other buffers in between)
+        # (the plan may have served another caller's buffers in between, and detect() may change the threshold per call: Plan._bound
+        # says what the head ops currently point at)
+        if self.compact is not None:
+            want = (self.compact[0].data_ptr(), float(self.step.conf_thres), self._ps)
+            if pl.__dict__.get("_bound") != want:
+                self.compact = (self.compact[0], float(self.step.conf_thres), self.compact[2])
+                pl._bind_outputs(None, self._ps, self.compact)
+        elif pl.__dict__.get("_bound") != (self.io.data_ptr(), None, self._ps):
             pl._bind_outputs(self.io, self._ps)
-            pl._bound_io = self.step.io
         # the whole-batch plans are shared with launch_detect's stream sets: same ordering rule as there
         if sp._full_mode:
             torch.cuda.synchronize(sp.device)

@@ -336,6 +336,34 @@ def nms_merge(pred, conf_thres, nms_thres, out_dets, out_idx, out_count, workspa
                                 stream_ptr()), "nms_merge")
 
 
+def nms_compact_workspace_bytes(bs, rows, nc) -> int:
+    return int(load().yolo_nms_compact_workspace_bytes(bs, rows, nc))
+
+
+def head_decode_filter(x, w_packed, bias, desc: YoloConvDesc, anchors_px, nc, stride_px, rows_total, io_row_offset, conf_thres,
+                       workspace, *, min_wh=2.0, p=None):
+    """Head conv + decode + NMS row filter in one launch (yolo_head_decode_filter_fwd): survivors go to ``workspace``."""
+    _need_cuda(x, w_packed, bias, workspace, p)
+    na = len(anchors_px)
+    flat = (C.c_float * (2 * na))(*[float(v) for a in anchors_px for v in a])
+    check(load().yolo_head_decode_filter_fwd(_ptr(x), _ptr(w_packed), _ptr(bias), C.byref(desc), flat, na, nc, float(stride_px),
+                                             rows_total, io_row_offset, float(conf_thres), float(min_wh), _ptr(workspace),
+                                             workspace.numel() * workspace.element_size(), _ptr(p), stream_ptr()), "head_decode_filter")
+
+
+def nms_merge_compact(workspace, bs, rows, nc, nms_thres, out_dets, out_idx, out_count, *, max_per_class=100):
+    """Sort / MERGE / final order over the survivors the head epilogues left in ``workspace`` (yolo_nms_merge_compact)."""
+    _need_cuda(workspace, out_dets, out_idx, out_count)
+    cap = out_dets.shape[1]
+    if tuple(out_dets.shape) != (bs, cap, 7) or tuple(out_idx.shape) != (bs, cap) or out_count.numel() != bs:
+        raise RuntimeError("nms: output shape mismatch")
+    if out_dets.dtype != torch.float32 or out_idx.dtype != torch.int32 or out_count.dtype != torch.int32:
+        raise RuntimeError("nms: output dtype mismatch")
+    check(load().yolo_nms_merge_compact(_ptr(workspace), workspace.numel() * workspace.element_size(), bs, rows, nc, float(nms_thres),
+                                        int(max_per_class), _ptr(out_dets), _ptr(out_idx), _ptr(out_count), cap, stream_ptr()),
+          "nms_merge_compact")
+
+
 def cu_masked_stream(cu_bits, device):
     """A torch stream (ExternalStream over hipExtStreamCreateWithCUMask) whose kernels run only on the listed CU
     indices (CU i sits on XCD i % 8).  The HIP stream lives as long as the process: it is never destroyed behind torch."""

@@ -392,6 +392,64 @@ def test_fused_head_decode(n, h, w, cin, k, nc, act):
     torch.testing.assert_close(p.cpu(), ref, rtol=1e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("n,h,w,cin,k,nc,act,conf", [(2, 20, 20, 256, 1, 80, "leaky", 0.05), (3, 13, 13, 512, 1, 80, "none", 0.1),
+                                                      (1, 10, 12, 64, 3, 80, "leaky", 0.02), (2, 8, 8, 72, 1, 3, "none", 0.2),
+                                                      (1, 26, 26, 128, 1, 20, "none", 0.1), (2, 14, 14, 96, 1, 80, "leaky", 0.001),
+                                                      (5, 3, 3, 64, 1, 1, "none", 0.3), (32, 2, 2, 128, 1, 80, "none", 0.01)])
+def test_head_decode_filter_is_the_plain_head_plus_nms(n, h, w, cin, k, nc, act, conf):
+    """The compact NMS form (round 4: yolo_head_decode_filter_fwd -> yolo_nms_merge_compact; detect()
+    never writes io) against the plain one (yolo_head_decode_fwd stores io, yolo_nms_merge filters and merges it) on the same
+    operands: counts, kept rows and all 7 columns BIT-EQUAL - the epilogue's row filter repeats nms_filter's arithmetic on the same
+    decoded values.  Cases: image boundaries inside a 64-pixel tile and several images per wave (3x3 and 2x2 maps), 8- and 4-wave
+    head tiles (cin 72 / 96), nc = 1 / 3 / 20 / 80, thresholds from 0.001 (nearly every row survives) to 0.3, a row offset and
+    foreign rows in io, and non-finite logits (a few +inf input values: rows with inf / NaN scores or boxes are dropped alike)."""
+    from pytorch_yolo_amd import kernels as K
+    from pytorch_yolo_amd._lib import ACT_LEAKY01, ACT_NONE, DT_F32
+    from pytorch_yolo_amd.utils.utils import MAX_PER_CLASS, MIN_WH, nms_capacity
+    na, no = 3, nc + 5
+    cout = na * no
+    anchors = [(10., 13.), (33., 23.), (59., 119.)]
+    stride = 16.0
+    g = torch.Generator().manual_seed(h * 7 + cin + n)
+    x = torch.randn(n, cin, h, w, generator=g)
+    flat = x.view(-1)
+    flat[torch.randint(0, flat.numel(), (max(1, flat.numel() // 5000),), generator=g)] = float("inf")
+    wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    xin = torch.zeros(n, h, w, cin + 8, dtype=torch.bfloat16, device=DEV)
+    xin[..., 8:] = _nhwc(x)
+    wp, bp, kpad, cout_pad = K.pack_conv_weight(wt, bias, cin)
+    wp, bp = wp.to(DEV), bp.to(DEV)
+    a = {"leaky": ACT_LEAKY01, "none": ACT_NONE}[act]
+    rows_total, row_off = na * h * w + 7, 5
+    d = K.conv_desc(n=n, h=h, w=w, cin=cin, in_c_total=cin + 8, in_c_offset=8, cout=cout, out_c_total=K.roundup(cout, 8),
+                    out_c_offset=0, ksize=k, stride=1, act=a, kpad=kpad, cout_pad=cout_pad, out_dtype=DT_F32)
+    cap = nms_capacity(rows_total, nc)
+    mk = lambda: (torch.full((n, cap, 7), -3.0, device=DEV), torch.full((n, cap), -3, dtype=torch.int32, device=DEV),
+                  torch.full((n,), -3, dtype=torch.int32, device=DEV))
+    # plain: io (foreign rows zero: they never survive) -> yolo_nms_merge
+    io = torch.zeros((n, rows_total, no), device=DEV)
+    K.head_decode(xin, wp, bp, d, anchors, nc, stride, io, row_off, None)
+    out_a = mk()
+    ws_a = torch.empty(K.nms_workspace_bytes(n, rows_total, nc), dtype=torch.uint8, device=DEV)
+    K.nms_merge(io, conf, 0.5, *out_a, ws_a, min_wh=MIN_WH, max_per_class=MAX_PER_CLASS)
+    # compact: the head filters its own rows, no io
+    ws_b = torch.full((K.nms_compact_workspace_bytes(n, rows_total, nc),), 0xCD, dtype=torch.uint8, device=DEV)
+    out_b = mk()
+    K.head_decode_filter(xin, wp, bp, d, anchors, nc, stride, rows_total, row_off, conf, ws_b, min_wh=MIN_WH)
+    K.nms_merge_compact(ws_b, n, rows_total, nc, 0.5, *out_b, max_per_class=MAX_PER_CLASS)
+    torch.cuda.synchronize()
+    cnt = out_a[2].cpu()
+    assert torch.equal(out_b[2].cpu(), cnt), (out_b[2].cpu().tolist(), cnt.tolist())
+    assert int(cnt.sum()) > 0, "the case is vacuous: nothing survives"
+    assert not bool(torch.isfinite(io).all()), "the case has no non-finite rows"
+    for b in range(n):
+        m = int(cnt[b])
+        assert torch.equal(out_a[1][b, :m], out_b[1][b, :m]), f"image {b}: kept rows differ"
+        assert torch.equal(out_a[0][b, :m], out_b[0][b, :m]), f"image {b}: detections differ"
+    print(f"[compact NMS {n}x{h}x{w} nc {nc} conf {conf}] detections per image {cnt.tolist()[:8]} - bit-equal to the plain form")
+
+
 @pytest.mark.parametrize("n,cin,h,w", [(2, 3, 64, 64), (1, 3, 70, 106), (1, 1, 37, 50), (2, 3, 192, 352), (1, 3, 2, 2), (1, 3, 33, 17),
                                         (3, 3, 416, 416), (40, 3, 96, 96)])
 def test_fused_stem(n, cin, h, w):
@@ -1661,9 +1719,17 @@ def test_headline_config_bs32_two_streams():
         dets = model.detect(xd, **C.NMS_FULL)
         # (round 4) a lone detect() runs ONE whole-batch list (engine.StreamedPlan.detect_step): the oracle NMS gets the io that
         # call produced (test_benched_launch_list_bs32_whole_batch holds that list against the reference)
-        fast = model.plan_for(xd).detect_step(**C.NMS_FULL)
-        assert fast is not None and fast._launched
-        io_c = fast.io.cpu()
+        plan = model.plan_for(xd)
+        fast = plan.detect_step(**C.NMS_FULL)
+        assert fast is not None and fast._launched and fast.io is None          # compact NMS form: that call wrote no io
+        io_w, _ = plan.new_outputs(want_p=False)                                # the same list once more, io materialised
+        from pytorch_yolo_amd.utils.utils import nms_capacity
+        cap = nms_capacity(plan.rows_total, model.n_class)
+        scratch = (torch.empty((32, cap, 7), device=DEV), torch.empty((32, cap), dtype=torch.int32, device=DEV),
+                   torch.empty((32,), dtype=torch.int32, device=DEV))
+        plan.launch_detect(xd, io_w, (None, None, None), scratch, join=False, whole_batch=True, **C.NMS_FULL)
+        torch.cuda.synchronize()
+        io_c = io_w.cpu()
     odets, _ = onms.non_max_suppression(io_c.numpy().copy(), **C.NMS_FULL)
     for b in range(32):
         assert (dets[b] is None) == (odets[b] is None)
@@ -1732,6 +1798,18 @@ def test_benched_launch_list_bs32_whole_batch(cu_partition):
         assert torch.equal(out[2].cpu(), n0)
         for b in range(32):
             assert torch.equal(out[0][b, :n0[b]], out0[0][b, :n0[b]])
+    # (f) what bench.py / detect() / detect_stream() actually run is the COMPACT form of these lists (the heads filter their own rows,
+    # io is never written): its detections are bit-equal to the ones the plain NMS made from the materialised io above
+    with torch.no_grad():
+        for call in range(2):
+            outc = (torch.full((32, cap, 7), -1.0, device=DEV), torch.zeros((32, cap), dtype=torch.int32, device=DEV),
+                    torch.zeros((32,), dtype=torch.int32, device=DEV))
+            plan.launch_detect(xd, None, (None, None, None), outc, C.NMS_FULL["conf_thres"], C.NMS_FULL["nms_thres"], join=False,
+                               whole_batch=True, cu_partition=cu_partition, compact=True)
+            torch.cuda.synchronize()
+            assert torch.equal(outc[2].cpu(), n0), "compact NMS form: counts differ from the plain form"
+            for b in range(32):
+                assert torch.equal(outc[0][b, :n0[b]], out0[0][b, :n0[b]]) and torch.equal(outc[1][b, :n0[b]], out0[1][b, :n0[b]])
     # (b)
     io_c = io0.cpu()
     _assert_model_close(io_c[:1][:, g["rows"]], torch.from_numpy(g["io_rows"]), "benched list, image 0 / golden rows", score_max=0.18, score_rms=1e-2)

@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--bs", type=int, default=0)
     ap.add_argument("--repeat", type=int, default=5)
     ap.add_argument("--launch-cus", type=int, default=0, help="CU count the tile rules plan for (default: 256, or 128 under --cu-mask half)")
+    ap.add_argument("--compact", action="store_true", help="heads in the compact NMS form (filter in the epilogue, no io store)")
+    ap.add_argument("--no-p", action="store_true", help="heads skip the raw p store (what detect() / bench.py run)")
     ap.add_argument("--cu-mask", default="", help="'half': time the ops on a stream that owns half of every XCD's CUs (YOLO_CU_PARTITION=split)")
     args = ap.parse_args()
     wl = bench.WORKLOADS[args.workload]
@@ -49,7 +51,11 @@ def main():
         K.set_launch_cus(args.launch_cus)
     plan = model.plan_for(x)
     plan.feed(x)
-    plan._bind_outputs(*plan.new_outputs())
+    if args.compact:
+        cws = plan.compact_workspace()
+        plan._bind_outputs(None, tuple(None for _ in plan.heads), (cws, bench.CONF_THRES, 2.0))
+    else:
+        plan._bind_outputs(*plan.new_outputs(want_p=not args.no_p))
     K.run_ops(plan.op_array, plan.n_ops)
     torch.cuda.synchronize()
     times = [[] for _ in range(plan.n_ops)]
