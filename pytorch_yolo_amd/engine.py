@@ -1287,12 +1287,21 @@ class StreamedPlan:
                 cur.wait_stream(st)
 
     def _make_nms_streams(self):
-        """One NMS side stream per pipeline, created at HIGH priority: the NMS of a batch (one 1024-thread workgroup per image,
-        latency-bound) is the tail of that batch and, for the small models, as long as a step of the layer list; behind the other
-        pipeline's queued conv workgroups at equal priority it waited for CUs, and on ONE shared stream the NMS of successive
-        batches ran one after the other (YOLOv3-tiny: 0.33 ms of NMS per 0.37 ms step)."""
+        """The NMS side stream, created at HIGH priority and shared by the pipelines: the NMS of a batch (one 1024-thread workgroup
+        per image, latency-bound) is the tail of that batch; at equal priority it waited for CUs behind the other pipeline's queued
+        conv workgroups.  ONE stream, not one per pipeline (YOLO_NMS_STREAMS=per-pipeline: no faster on any workload, 88.3 k vs
+        87.1 k images/s on YOLOv3-tiny): every HIP stream that has been used owns a hardware queue, and with the default stream,
+        the two pipeline streams, two NMS streams and - created last - the two CU-masked streams of ``launch_detect(cu_partition=True)``
+        the process held more queues than the scheduler runs side by side: the partitioned loop dropped from 6,600 to 5,720 images/s
+        whenever ``detect_stream()`` had run before it (tools/dbg/stream_then_loop.py; GPU_MAX_HW_QUEUES = 12 / 16 changed nothing,
+        one queue fewer restored it)."""
         if self._nms_streams is None:
-            self._nms_streams = [torch.cuda.Stream(device=self.device, priority=-1) for _ in self.streams]
+            prio = int(os.environ.get("YOLO_NMS_PRIORITY", "-1"))
+            if os.environ.get("YOLO_NMS_STREAMS", "1") == "1":
+                one = torch.cuda.Stream(device=self.device, priority=prio)
+                self._nms_streams = [one for _ in self.streams]
+            else:
+                self._nms_streams = [torch.cuda.Stream(device=self.device, priority=prio) for _ in self.streams]
             self._nms_stream = self._nms_streams[0]
 
     # -- the one-call pipeline step (yolo_pipeline_step): what detect_stream() launches per batch ------------------------------

@@ -1216,6 +1216,28 @@ def test_forward_idempotent_and_graph_replay():
     assert all(torch.equal(a, b) for a, b in zip(p1, p3))
 
 
+def test_graph_replay_at_the_tiny416_bench_shape():
+    """``use_hip_graph`` on the configuration whose per-pipeline graph experiment ended in a GPU memory access fault in round 3
+    (YOLOv3-tiny 416x416, 32 images, two sub-batch streams captured into one HIP graph): replay == eager, bit for bit, twice, and
+    with another input.  (The launch lists of this shape passed the red-zone audit - test_launch_lists_stay_inside_their_buffers -
+    and the static one; the experiment's own capture code was never committed.)"""
+    case = C.FULL_CASES["tiny_416"]
+    model, sd, _ = build_case(case)
+    model = model.to(DEV)
+    xa, xb = _seeded_batch(32, 416).to(DEV), _seeded_batch(32, 416, first_seed=200).to(DEV)
+    with torch.no_grad():
+        assert type(model.plan_for(xa)).__name__ == "StreamedPlan"
+        io_a, p_a = model(xa)
+        io_b, _ = model(xb)
+        model.use_hip_graph = True
+        g1 = model(xa)[0].clone()
+        g2 = model(xb)[0].clone()
+        g3 = model(xa)
+        torch.cuda.synchronize()
+    assert torch.equal(g1, io_a) and torch.equal(g2, io_b) and torch.equal(g3[0], io_a)
+    assert all(torch.equal(a, b) for a, b in zip(g3[1], p_a))
+
+
 def test_concurrent_streams_give_identical_results():
     """engine.StreamedPlan: sub-batches on 2 HIP streams == one launch list, bit for bit."""
     from pytorch_yolo_amd.utils.synthetic import synth_images
