@@ -243,6 +243,10 @@ def main():
     ap.add_argument("--pipeline", default="batches", choices=["batches", "halves"],
                     help="what a pipeline carries: whole batches, successive steps alternating between the pipelines (default), or "
                          "one sub-batch of every step each")
+    ap.add_argument("--cu-partition", action="store_true",
+                    help="give each pipeline half of every XCD's CUs (hipExtStreamCreateWithCUMask) and size its grids for them: the "
+                         "default of rounds 2-3 (+1.0 %% then); since the compact NMS form and the high-priority NMS stream of round 4 "
+                         "the shared chip is faster (6,545 vs 6,459 images/s, three interleaved pairs on one box), so it is off")
     ap.add_argument("--materialize-io", action="store_true",
                     help="store io and run the plain NMS on it (A/B of the compact NMS form, which is the default: the heads filter "
                          "their own rows and detect() never writes io)")
@@ -336,8 +340,8 @@ def main():
         calls[0] += 1
         tm = ev[i] if timed else None
         if gatherer is None:
-            plan.launch_detect(x, io, ps, nms_out, CONF_THRES, NMS_THRES, timing=tm, join=False, whole_batch=whole, cu_partition=True,
-                               compact=not args.materialize_io)
+            plan.launch_detect(x, io, ps, nms_out, CONF_THRES, NMS_THRES, timing=tm, join=False, whole_batch=whole,
+                               cu_partition=args.cu_partition, compact=not args.materialize_io)
             return nms_out[0], nms_out[2]
         plan.launch_detect(x, io, ps, nms_out, CONF_THRES, NMS_THRES, timing=tm, join=False, whole_batch=whole,
                            after_nms=gatherer.begin(nms_out), compact=not args.materialize_io)
@@ -506,7 +510,7 @@ def main():
             "config": cfg,
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes": plan.algorithmic_bytes() if not hasattr(plan, "_full") or plan._full is None else plan._full[0].algorithmic_bytes(),
+                         "algorithmic_bytes": (plan if not hasattr(plan, "_full") or plan._full is None else plan._full[0]).algorithmic_bytes(detect=not args.materialize_io),
                          "kernel": "conv-family launch lists of the forward (stem, fused residual units, conv3x3_t20v2, conv3x3s2_t20, conv_igemm_bf16 / "
                                    "conv1x1_stream incl. head+decode); per step: HIP-event span from the first timed list's start to the last "
                                    "lists' end / timed steps (the pipelines' lists overlap; nothing is assumed about how well)",
@@ -516,7 +520,7 @@ def main():
         if args.workload != "spp":
             # The small models are not MFMA work: 13..80 launches of 10..100 us whose bytes, not FLOPs, bound them.  Their line is
             # priced against HBM: algorithmic bytes of the launch list (engine.Plan.algorithmic_bytes) over its event time.
-            abytes = plan.algorithmic_bytes()
+            abytes = plan.algorithmic_bytes(detect=not args.materialize_io)
             gbs = abytes / (conv_ms_avg * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                                "traffic": traffic, "traffic_source": traffic_src,

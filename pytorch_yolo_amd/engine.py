@@ -957,10 +957,11 @@ class Plan:
                 total += (2.0 * d.n * d.h * d.w * d.cin * hid if op.w_pre else 0.0) + 2.0 * d.n * d.ho * d.wo * hid * (9 + d.cout)
         return total
 
-    def algorithmic_bytes(self) -> float:
+    def algorithmic_bytes(self, detect: bool = False) -> float:
         """HBM bytes one pass must move if every tensor that exists in HBM is read once and written once:
         per launch its input view, its output (x4 for a 2x2-replicated store, fp32 head rows + decoded rows for a fused head),
-        the residual and the pre-add copy, and its weights.  Fused launches count only what crosses the chip boundary."""
+        the residual and the pre-add copy, and its weights.  Fused launches count only what crosses the chip boundary.
+        ``detect=True``: the pass of ``detect()`` in the compact NMS form - a head writes one 8-byte key per row instead of p and io."""
         total = 0.0
         first = True
         for i in range(self.n_ops):
@@ -974,6 +975,8 @@ class Plan:
                 y_b = m_out * d.cout * (4 if d.out_dtype else 2) * (4 if d.upsample2x else 1) / pooled
                 if op.kind == OP_HEAD_DECODE:
                     y_b = 2.0 * m_out * d.cout * 4                                   # p (raw) + io (decoded), fp32
+                    if detect:
+                        y_b = m_out * op.head_na * 8.0                               # one sort key per (pixel, anchor) row
                 total += x_b + y_b + d.cout * d.ksize * d.ksize * d.cin * 2
                 total += (m_out * d.cout * 2 if op.residual else 0) + (m_out * d.cout * 2 if op.y_aux else 0)
             elif op.kind == OP_STEM:
@@ -1348,8 +1351,8 @@ class StreamedPlan:
     def activation_bytes(self) -> int:
         return sum(p.activation_bytes() for p in self.subs)
 
-    def algorithmic_bytes(self) -> float:
-        return sum(p.algorithmic_bytes() for p in self.subs)
+    def algorithmic_bytes(self, detect: bool = False) -> float:
+        return sum(p.algorithmic_bytes(detect) for p in self.subs)
 
 
 StreamedPlan.run_graph = Plan.run_graph

@@ -1,13 +1,8 @@
 #!/bin/bash
-# Round-4 evidence at HEAD on one box: GPU suite, bench lines of every workload, kernel statistics, PMC traffic (two separate passes) and
-# the MFMA-busy pass of the headline command, per-layer tables.   bash tools/r4_profiles.sh   -> gpurun_out/r4p_*
+# Round-4 evidence at HEAD on one box: kernel statistics, PMC traffic (two separate passes: FETCH_SIZE takes 3 of the 4 TCC slots) and the
+# MFMA-busy pass of the headline command, per-layer tables.   bash tools/r4_profiles.sh   -> gpurun_out/r4p_*   (program directly after --)
 cd $GRAFT_REPO_ROOT
 O=gpurun_out
-python -m pytest tests -x -q -m gpu > $O/r4p_gpu_suite.log 2>&1; echo "suite rc $?"; tail -2 $O/r4p_gpu_suite.log
-python bench.py --steps 100 --warmup 10 > $O/r4p_bench_spp.json 2> $O/r4p_bench_spp.err; echo "bench spp rc $?"; cut -c1-230 $O/r4p_bench_spp.json
-for wl in tiny mobile efficient; do
-  python bench.py --workload $wl --steps 200 --warmup 20 > $O/r4p_bench_$wl.json 2> $O/r4p_bench_$wl.err; echo "bench $wl rc $?"; cut -c1-200 $O/r4p_bench_$wl.json
-done
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for WL in spp tiny mobile; do
   rm -rf $O/r4p_pmc_${WL}_f $O/r4p_pmc_${WL}_w $O/r4p_kstats_${WL}
@@ -18,8 +13,7 @@ done
 rm -rf $O/r4p_pmc_spp_mfma
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/r4p_pmc_spp_mfma -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-api --no-sustained > $O/r4p_pmc_spp_mfma.json 2> $O/r4p_pmc_spp_mfma.err; echo "mfma pass rc $?"
 python tools/layer_profile.py --workload spp --bs 32 --compact > $O/r4p_layers_spp.txt 2>&1
-python tools/layer_profile.py --workload spp --bs 32 --compact --cu-mask half > $O/r4p_layers_spp_half.txt 2>&1
 python tools/layer_profile.py --workload tiny --compact > $O/r4p_layers_tiny.txt 2>&1
 python tools/layer_profile.py --workload mobile --compact > $O/r4p_layers_mobile.txt 2>&1
-tail -1 $O/r4p_layers_spp.txt $O/r4p_layers_tiny.txt
-find $O/r4p_pmc_spp_f $O/r4p_kstats_spp -name "*.csv" | head -4
+grep total $O/r4p_layers_spp.txt $O/r4p_layers_tiny.txt $O/r4p_layers_mobile.txt
+grep -c . $O/r4p_pmc_spp_f/*/*counter_collection.csv
