@@ -246,7 +246,7 @@ def main():
     ap.add_argument("--cu-partition", action="store_true",
                     help="give each pipeline half of every XCD's CUs (hipExtStreamCreateWithCUMask) and size its grids for them: the "
                          "default of rounds 2-3 (+1.0 %% then); since the compact NMS form and the high-priority NMS stream of round 4 "
-                         "the shared chip is faster (6,545 vs 6,459 images/s, three interleaved pairs on one box), so it is off")
+                         "the shared chip is as fast or faster (6,604 vs 6,593 and 6,545 vs 6,459 images/s on two boxes), so it is off")
     ap.add_argument("--materialize-io", action="store_true",
                     help="store io and run the plain NMS on it (A/B of the compact NMS form, which is the default: the heads filter "
                          "their own rows and detect() never writes io)")

@@ -915,8 +915,9 @@ class Plan:
                 K.decode(hd["sym"].buf.tensor, hd["anchors"], self.n_class, hd["stride"], io, hd["row"], p)
 
     def launch_detect(self, x, io, ps, nms_out, conf_thres, nms_thres, timing=None, join=True, after_nms=None, whole_batch=False,
-                      wait_for=None, compact=False):
-        """forward + decode + MERGE-NMS into caller-provided buffers; no host sync.  ``compact=True``: the compact NMS form
+                      wait_for=None, compact=False, cu_partition=False):
+        """forward + decode + MERGE-NMS into caller-provided buffers; no host sync (``cu_partition`` / ``whole_batch`` / ``join`` are
+        the StreamedPlan's: one list on the current stream has nothing to partition).  ``compact=True``: the compact NMS form
         (``io`` is not written and may be None; include/yolo_hip.h yolo_head_decode_filter_fwd) where the plan allows it.
         nms_out = (dets [bs,cap,7] f32, idx [bs,cap] i32, count [bs] i32).  ``timing``: one (start, end)
         event pair per stream, recorded around the conv launch list.  ``after_nms(i, lo, hi)`` is called in

@@ -2633,7 +2633,7 @@ def test_detect_stream_yields_every_batch_in_order():
             assert (a is None) == (b is None) and (a is None or torch.equal(a, b))
 
 
-@pytest.mark.parametrize("extra", [(), ("--pipeline", "halves", "--no-api")])
+@pytest.mark.parametrize("extra", [(), ("--pipeline", "halves", "--no-api"), ("--streams", "1", "--no-api")])
 def test_bench_line_contract(extra):
     """bench.py as the driver runs it (a child process, one JSON line on stdout): the contract keys, the roofline object and the
     echo of --steps / --warmup, on the small workload in both pipeline modes."""
@@ -2657,7 +2657,8 @@ def test_bench_line_contract(extra):
         assert k in rf, k
     assert rf["bound"] in ("hbm", "mfma") and 0 < rf["frac"] < 1 and abs(rf["achieved"] / rf["peak"] - rf["frac"]) < 1e-3
     assert "workload" in d["config"] and "model" not in d["config"]
-    assert d["config"]["pipelines"].startswith("2 x " + ("sub-batches" if extra else "whole batches"))
+    if "--streams" not in extra:
+        assert d["config"]["pipelines"].startswith("2 x " + ("sub-batches" if extra else "whole batches"))
     assert d["config"]["mean_detections_per_image"] > 0
     assert rf["ms_per_step_layers" if rf["bound"] == "hbm" else "ms_per_step_conv"] <= d["ms_per_step"] * 1.02      # a measured span, not an assumption
     assert d["config"]["sustained_images_per_s"] > 0
