@@ -293,7 +293,12 @@ static_assert(2 * 32 * kV2Pitch <= 2 * kPlaneB, "epilogue buffers reuse the plan
 // three planes in flight, 119 KB, one workgroup per CU) was measured for the grids that give a CU one workgroup anyway and is NOT
 // instantiated: 0.133 vs 0.125 ms on the 40 -> 20 layer at 32 images - with one wave per SIMD the MFMA stream itself, not the plane
 // fetch, is what stalls, and the gather kernel's 16-wave tiles do as well there; such grids stay with it (launch rule below).
-template <int XD, int RD, int NBUF, bool LEAKY>
+// PAIR (round 4, layers with an even number of 32-channel chunks): the steps of TWO chunks are interleaved plane by plane - plane 0 of
+// chunk 2 p, plane 0 of chunk 2 p + 1, plane 1 of chunk 2 p, ... - because the chunks 2 p and 2 p + 1 of a pixel are the two 64-byte
+// halves of ONE 128-byte line: fetched a whole chunk (four plane blocks) apart, the second half came from HBM again (the counters read
+// 1.8 x the layer's input on the 320 -> 160 layer, whose 0.19 ms were exactly that traffic at 5.5 TB/s); fetched one plane block apart
+// it is an L2 hit.  Same planes, taps, accumulators and weight stream: only the order of the 18 (chunk, tap) steps of a pair changes.
+template <int XD, int RD, int NBUF, bool LEAKY, bool PAIR = false>
 __global__ __launch_bounds__(256, 2) void conv3x3s2_t20_kernel(const ConvArgs a) {
   constexpr int NP = 25, PPW = 7, AHEAD = NBUF - 1;         // planes requested ahead of the one being multiplied
   static_assert(NBUF == 2 || NBUF == 4, "plane buffers");
@@ -398,43 +403,93 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_t20_kernel(const ConvArgs a)
   wait_vmcnt<4 + 7 * (AHEAD - 1)>();                   // plane 0 of chunk 0 has landed (later planes and the four weight loads may still fly)
   __builtin_amdgcn_s_barrier();
 
-  for (int c = 0; c < nch; ++c) {
-    static_for<9>([&](auto sc) {
-      constexpr int st = decltype(sc)::value, pl = ST_PLANE[st];
-      constexpr bool first = st == 0 || ST_PLANE[st > 0 ? st - 1 : 0] != pl, last = st == 8 || ST_PLANE[st < 8 ? st + 1 : 8] != pl;
-      if constexpr (first) {
-        // behind the barrier that ended the plane before: the buffer it used takes the plane AHEAD planes on (beyond the last
-        // chunk dummy ones, so that the counted waits stay uniform; they read inside the input buffer or return zeros)
-        constexpr int npl = (pl + AHEAD) & 3;
-        issue_plane(npl % NBUF, pl + AHEAD > 3 ? c + 1 : c, PL_RY[npl], PL_RX[npl]);
-      }
-      {
-        constexpr int s2 = (st + 2) % 9;
-        const int c2 = c + (st + 2) / 9;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) wf[(st + 2) % 3][i] = wload(c2, ST_TAP[s2], i);
-      }
-      const uint32_t am = A[ST_SY[st]];
-      if constexpr (first) {                           // a new plane buffer: nothing of it could be fetched before the barrier
-#pragma unroll
-        for (int j = 0; j < XD - 1; ++j) xf[(j + (st * NP) % XD) % XD] = xread(j, st, am);
-      }
-      static_for<NP>([&](auto jc) {
-        constexpr int jj = decltype(jc)::value;
-        constexpr int R = (st * NP) % XD;              // patch jj of step st lives in xf[(jj + st * NP) % XD] (NP % XD == 1)
-        if constexpr (jj + XD - 1 < NP) xf[(jj + XD - 1 + R) % XD] = xread(jj + XD - 1, st, am);
-        else if constexpr (!last) xf[(jj + XD - 1 + R) % XD] = xread(jj + XD - 1 - NP, st < 8 ? st + 1 : 8, A[ST_SY[st < 8 ? st + 1 : 8]]);   // the next step's first ones (same plane)
-        static_for<2>([&](auto ic) { mfma(ic, jc, wf[st % 3][decltype(ic)::value], xf[(jj + R) % XD]); });
+  if constexpr (!PAIR) {
+    for (int c = 0; c < nch; ++c) {
+      static_for<9>([&](auto sc) {
+        constexpr int st = decltype(sc)::value, pl = ST_PLANE[st];
+        constexpr bool first = st == 0 || ST_PLANE[st > 0 ? st - 1 : 0] != pl, last = st == 8 || ST_PLANE[st < 8 ? st + 1 : 8] != pl;
+        if constexpr (first) {
+          // behind the barrier that ended the plane before: the buffer it used takes the plane AHEAD planes on (beyond the last
+          // chunk dummy ones, so that the counted waits stay uniform; they read inside the input buffer or return zeros)
+          constexpr int npl = (pl + AHEAD) & 3;
+          issue_plane(npl % NBUF, pl + AHEAD > 3 ? c + 1 : c, PL_RY[npl], PL_RX[npl]);
+        }
+        {
+          constexpr int s2 = (st + 2) % 9;
+          const int c2 = c + (st + 2) / 9;
+  #pragma unroll
+          for (int i = 0; i < 2; ++i) wf[(st + 2) % 3][i] = wload(c2, ST_TAP[s2], i);
+        }
+        const uint32_t am = A[ST_SY[st]];
+        if constexpr (first) {                           // a new plane buffer: nothing of it could be fetched before the barrier
+  #pragma unroll
+          for (int j = 0; j < XD - 1; ++j) xf[(j + (st * NP) % XD) % XD] = xread(j, st, am);
+        }
+        static_for<NP>([&](auto jc) {
+          constexpr int jj = decltype(jc)::value;
+          constexpr int R = (st * NP) % XD;              // patch jj of step st lives in xf[(jj + st * NP) % XD] (NP % XD == 1)
+          if constexpr (jj + XD - 1 < NP) xf[(jj + XD - 1 + R) % XD] = xread(jj + XD - 1, st, am);
+          else if constexpr (!last) xf[(jj + XD - 1 + R) % XD] = xread(jj + XD - 1 - NP, st < 8 ? st + 1 : 8, A[ST_SY[st < 8 ? st + 1 : 8]]);   // the next step's first ones (same plane)
+          static_for<2>([&](auto ic) { mfma(ic, jc, wf[st % 3][decltype(ic)::value], xf[(jj + R) % XD]); });
+        });
+        if constexpr (last) {
+          // The next plane has landed when at most the youngest AHEAD - 1 plane requests and the weight loads of the coming steps are
+          // still out (behind its DMAs this plane issued two weight loads per step; two steps' worth - one step's for the one-tap
+          // plane - belong to steps not yet multiplied).  Vector-memory operations retire in issue order.
+          constexpr int nsteps = pl == 0 ? 4 : (pl == 3 ? 1 : 2);
+          wait_vmcnt<(nsteps >= 2 ? 4 : 2) + 7 * (AHEAD - 1)>();
+          __builtin_amdgcn_s_barrier();
+        }
       });
-      if constexpr (last) {
-        // The next plane has landed when at most the youngest AHEAD - 1 plane requests and the weight loads of the coming steps are
-        // still out (behind its DMAs this plane issued two weight loads per step; two steps' worth - one step's for the one-tap
-        // plane - belong to steps not yet multiplied).  Vector-memory operations retire in issue order.
-        constexpr int nsteps = pl == 0 ? 4 : (pl == 3 ? 1 : 2);
-        wait_vmcnt<(nsteps >= 2 ? 4 : 2) + 7 * (AHEAD - 1)>();
-        __builtin_amdgcn_s_barrier();
-      }
-    });
+    }
+  } else {
+    static_assert(NBUF == 2, "pair order: two plane buffers");
+    // the 18 steps of a chunk pair: blocks (plane, chunk of the pair) = (0,0) (0,1) (1,0) (1,1) (2,0) (2,1) (3,0) (3,1); block k uses
+    // plane buffer k % 2 and requests block k + 1's plane behind the barrier that ended block k - 1
+    constexpr int PB_PLANE[8] = {0, 0, 1, 1, 2, 2, 3, 3}, PB_CH[8] = {0, 1, 0, 1, 0, 1, 0, 1}, PB_FIRST[9] = {0, 4, 8, 10, 12, 14, 16, 17, 18};
+    constexpr int PS_BLOCK[18] = {0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 7};
+    constexpr int PS_TAP[18] = {0, 2, 6, 8, 0, 2, 6, 8, 3, 5, 3, 5, 1, 7, 1, 7, 4, 4};
+    constexpr int PS_SY[18] = {0, 0, 1, 1, 0, 0, 1, 1, 0, 0, 0, 0, 0, 1, 0, 1, 0, 0};
+    constexpr int PS_SX[18] = {0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0};
+    auto xread2 = [&](int jj, int s_, uint32_t am) -> bf16x8 {
+      const char* const p = smem + am;
+      return *reinterpret_cast<const bf16x8*>(p + (PS_BLOCK[s_] & 1) * kPlaneB + ((4 * (jj / 5) + PS_SY[s_]) * kPW + 4 * (jj % 5) + PS_SX[s_]) * 64);
+    };
+    const int npairs = nch >> 1;
+    for (int cp = 0; cp < npairs; ++cp) {
+      static_for<18>([&](auto sc) {
+        constexpr int st = decltype(sc)::value, blk = PS_BLOCK[st];
+        constexpr bool first = st == PB_FIRST[blk], last = st + 1 == PB_FIRST[blk + 1];
+        if constexpr (first) {
+          // the buffer of the block before takes the NEXT block's plane (behind the last pair a dummy one: the counted waits stay uniform)
+          constexpr int nb = (blk + 1) & 7;
+          issue_plane(nb & 1, 2 * (blk == 7 ? cp + 1 : cp) + PB_CH[nb], PL_RY[PB_PLANE[nb]], PL_RX[PB_PLANE[nb]]);
+        }
+        {
+          constexpr int s2 = (st + 2) % 18;
+          const int c2 = 2 * (cp + (st + 2) / 18) + PB_CH[PS_BLOCK[s2]];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) wf[(st + 2) % 3][i] = wload(c2, PS_TAP[s2], i);
+        }
+        const uint32_t am = A[PS_SY[st]];
+        if constexpr (first) {                           // a new plane buffer: nothing of it could be fetched before the barrier
+#pragma unroll
+          for (int j = 0; j < XD - 1; ++j) xf[(j + (st * NP) % XD) % XD] = xread2(j, st, am);
+        }
+        static_for<NP>([&](auto jc) {
+          constexpr int jj = decltype(jc)::value;
+          constexpr int R = (st * NP) % XD;              // patch jj of step st lives in xf[(jj + st * NP) % XD] (NP % XD == 1)
+          if constexpr (jj + XD - 1 < NP) xf[(jj + XD - 1 + R) % XD] = xread2(jj + XD - 1, st, am);
+          else if constexpr (!last) xf[(jj + XD - 1 + R) % XD] = xread2(jj + XD - 1 - NP, st < 17 ? st + 1 : 17, A[PS_SY[st < 17 ? st + 1 : 17]]);   // the next step's first ones (same block)
+          static_for<2>([&](auto ic) { mfma(ic, jc, wf[st % 3][decltype(ic)::value], xf[(jj + R) % XD]); });
+        });
+        if constexpr (last) {
+          constexpr int nsteps = PB_FIRST[blk + 1] - PB_FIRST[blk];
+          wait_vmcnt<(nsteps >= 2 ? 4 : 2)>();           // the next block's plane has landed; the weight loads of the coming steps may still fly
+          __builtin_amdgcn_s_barrier();
+        }
+      });
+    }
   }
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("s_nop 15\n\ts_nop 15");              // the last asm MFMAs' D registers: 12 wait states before any other reader
@@ -451,7 +506,13 @@ int launch_t20s2(const ConvArgs& a, hipStream_t s) {
   const long grid = (long)a.d.n * ((a.d.ho + kT20 - 1) / kT20) * ((a.d.wo + kT20 - 1) / kT20) * b.n_tiles;
   if (grid > 0x7fffffffL) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv grid too large");
   if (pick_only("t20s2<400px x 128 couts, 4 waves, parity planes> grid %ld", grid)) return 0;
-  if (a.d.act == YOLO_ACT_LEAKY01) hipLaunchKernelGGL((conv3x3s2_t20_kernel<3, 3, 2, true>), dim3((unsigned)grid), dim3(256), 0, s, b);
+  // (chunk pairs where the layer has an even number of 32-channel chunks: every stride-2 layer of YOLOv3-SPP; YOLO_CONV_DEBUG bit
+  // 16777216 keeps the chunk-by-chunk order for A/Bs)
+  const bool pair = (a.d.cin / 32) % 2 == 0 && !(a.debug & 16777216);
+  if (pair) {
+    if (a.d.act == YOLO_ACT_LEAKY01) hipLaunchKernelGGL((conv3x3s2_t20_kernel<3, 3, 2, true, true>), dim3((unsigned)grid), dim3(256), 0, s, b);
+    else hipLaunchKernelGGL((conv3x3s2_t20_kernel<3, 3, 2, false, true>), dim3((unsigned)grid), dim3(256), 0, s, b);
+  } else if (a.d.act == YOLO_ACT_LEAKY01) hipLaunchKernelGGL((conv3x3s2_t20_kernel<3, 3, 2, true>), dim3((unsigned)grid), dim3(256), 0, s, b);
   else hipLaunchKernelGGL((conv3x3s2_t20_kernel<3, 3, 2, false>), dim3((unsigned)grid), dim3(256), 0, s, b);
   return yolo_check_launch("yolo_conv2d_fwd(t20s2)");
 }

@@ -2258,6 +2258,9 @@ T20S2_CASES = [
     (3, 75, 83, 96, 256, True),           # odd input sizes: outputs 38 x 42, partial tiles on both edges, three chunks
     (2, 41, 40, 32, 128, False),          # one chunk: prologue and the dummy plane only; odd height (the last input row is used)
     (1, 160, 160, 128, 256, False),       # 16 tiles per image
+    # (round 4: layers with an even number of chunks run the chunk-PAIR step order - cases 1, 2, 5 above -, odd ones - 3 and 1 chunks -
+    # the chunk-by-chunk order)
+    (1, 150, 146, 512, 128, True),        # 16 chunks = 8 pairs, partial tiles
 ]
 
 
