@@ -201,8 +201,14 @@ YOLO_API int yolo_stem_fwd(const float* x_nchw, int cin_real, const void* w1_pac
  *           no expand conv, hidden == cin);  b_exp f32 [ce]
  *    w_dw   f32 [9][ce] tap-major, b_dw f32 [ce]  (zero beyond hidden)
  *    w_proj bf16 [cout_pad][dstride/2]: row = output channel, the first hidden entries real;  b_proj f32 [cout_pad]
- *  has_res: y = x + ... (stride 1, cin == cout).  yolo_mbconv_supported(): cin <= 32, hidden <= 192, cout <= 64;
- *  other blocks run as yolo_conv2d_fwd + yolo_dwconv3x3_fwd + yolo_conv2d_fwd. */
+ *  has_res: y = x + ... (stride 1, cin == cout).
+ *  yolo_mbconv_supported() returns the FORM that covers a block, which decides the weight images:
+ *    1  cin <= 32, hidden <= 192, cout <= 64 (the blocks on the 208..52 maps of a 416x416 input): the images above;
+ *    2  the wide blocks (csrc/conv_mbwide.hip: the hidden dimension streamed in chunks of 64 channels): cin a multiple of 32
+ *       in 64..160 (stride 2: ..96), hidden a multiple of 64, cout <= 320, expand conv present.  Plain row-major matrices,
+ *       read through buffer descriptors:  w_exp bf16 [hidden][cin], b_exp f32 [hidden], w_dw f32 [9][hidden], b_dw f32 [hidden],
+ *       w_proj bf16 [cout_pad][hidden], b_proj f32 [cout_pad];
+ *    0  not covered: the block runs as yolo_conv2d_fwd + yolo_dwconv3x3_fwd + yolo_conv2d_fwd. */
 typedef struct YoloMbconvDesc {
   int32_t n, h, w, cin, in_c_total, in_c_offset, hidden, cout, out_c_total, out_c_offset, stride, has_expand, has_res, _pad;
 } YoloMbconvDesc;

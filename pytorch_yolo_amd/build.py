@@ -24,6 +24,7 @@ SOURCES = {
     "conv_resunit_t20.hip": [],
     "conv_stem.hip": [],
     "conv_mbconv.hip": [],
+    "conv_mbwide.hip": [],
     "conv_small.hip": [],
     "conv_f32.hip": ["-ffp-contract=off"],
     "conv1x1_stream.hip": [],

@@ -292,10 +292,18 @@ extern "C" int yolo_mbconv_dstride(int ce) {
   return s;
 }
 
+// the wide blocks (hidden dimension streamed in chunks): conv_mbwide.hip
+int yolo_mbwide_supported(int cin, int hidden, int cout, int stride);
+int yolo_mbwide_launch(const void* x, const void* w_exp, const float* b_exp, const float* w_dw, const float* b_dw, const void* w_proj,
+                       const float* b_proj, void* y, const YoloMbconvDesc& d, hipStream_t st);
+
+// 0: not covered; 1: the whole hidden tile in LDS (this file); 2: the wide form (conv_mbwide.hip) - the two take different weight images
 extern "C" int yolo_mbconv_supported(int cin, int hidden, int cout, int stride) {
   const int ce = (hidden + 31) / 32 * 32;
-  return cin >= 8 && cin <= 32 && cin % 8 == 0 && hidden % 4 == 0 && hidden >= cin && ce <= 192 && cout >= 4 && cout <= 64 &&
-         cout % 4 == 0 && (stride == 1 || stride == 2);
+  if (cin >= 8 && cin <= 32 && cin % 8 == 0 && hidden % 4 == 0 && hidden >= cin && ce <= 192 && cout >= 4 && cout <= 64 &&
+      cout % 4 == 0 && (stride == 1 || stride == 2))
+    return 1;
+  return yolo_mbwide_supported(cin, hidden, cout, stride) ? 2 : 0;
 }
 
 extern "C" int yolo_mbconv_fwd(const void* x, const void* w_exp, const float* b_exp, const float* w_dw, const float* b_dw,
@@ -309,6 +317,10 @@ extern "C" int yolo_mbconv_fwd(const void* x, const void* w_exp, const float* b_
   YOLO_REQUIRE(d.in_c_offset % 8 == 0 && d.in_c_total % 8 == 0 && d.in_c_offset + d.cin <= d.in_c_total, "mbconv: bad input view");
   YOLO_REQUIRE(d.out_c_offset % 4 == 0 && d.out_c_total % 4 == 0 && d.out_c_offset + d.cout <= d.out_c_total, "mbconv: bad output view");
   YOLO_REQUIRE(d.n > 0 && d.h > 0 && d.w > 0, "mbconv: empty input");
+  if (yolo_mbconv_supported(d.cin, d.hidden, d.cout, d.stride) == 2) {
+    YOLO_REQUIRE(d.has_expand, "mbconv: the wide form needs the expand conv");
+    return yolo_mbwide_launch(x, w_exp, b_exp, w_dw, b_dw, w_proj, b_proj, y, d, (hipStream_t)s);
+  }
   MbArgs a;
   a.x = (const bf16_t*)x;
   a.y = (bf16_t*)y;

@@ -298,7 +298,9 @@ class Plan:
         # 2c. MobileNetV2 inverted-residual blocks (1x1 expand + ReLU6, depthwise 3x3 + ReLU6, linear 1x1 [+ x]) with
         #     few channels, i.e. the large maps: one launch (yolo_mbconv_fwd), the 6x-expanded tensor and the
         #     depthwise output never exist in HBM; the output gets its own buffer (neighbouring tiles read x)
-        if os.environ.get("YOLO_FUSE_MBCONV", "1") == "1" and not self.f32:
+        #     YOLO_FUSE_MBCONV: "1" all covered blocks, "narrow" only those of csrc/conv_mbconv.hip (hidden <= 192), "0" none
+        mb_mode = os.environ.get("YOLO_FUSE_MBCONV", "1")
+        if mb_mode != "0" and not self.f32:
             for nd in nodes:
                 if (nd.kind != "conv" or "up_into" in nd.attrs or len(nd.outs) != 1 or nd.outs[0].f32
                         or nd.attrs["act"] != "none" or nd.attrs["stride"] != 1 or nd.attrs["weight"][0].shape[2] != 1):
@@ -315,7 +317,8 @@ class Plan:
                 x = ex.srcs[0] if has_exp else esym
                 if x is self.rec.input or x.f32 or (nd.attrs["has_res"] and nd.srcs[1] is not x):
                     continue
-                if K.mbconv_supported(x.c, esym.c, nd.attrs["weight"][0].shape[0], dwn.attrs["stride"]):
+                form = K.mbconv_form(x.c, esym.c, nd.attrs["weight"][0].shape[0], dwn.attrs["stride"])
+                if form == 1 or (form == 2 and has_exp and mb_mode != "narrow"):
                     nd.attrs["mb_pre"] = (ex if has_exp else None, dwn, x)
                     dwn.attrs["fused_away"] = True
                     if has_exp:
@@ -635,7 +638,7 @@ class Plan:
                 y = nd.outs[0]
                 hidden = dwn.srcs[0].c
                 we_b = ex.attrs["weight"] if ex is not None else (None, None)
-                packed = K.pack_mbconv(we_b[0], we_b[1], *dwn.attrs["weight"], *nd.attrs["weight"])
+                packed = K.pack_mbconv(we_b[0], we_b[1], *dwn.attrs["weight"], *nd.attrs["weight"], stride=dwn.attrs["stride"])
                 we, be, wd, bd, wp, bp = (None if t is None else self._dev(t) for t in packed)
                 op = YoloOp()
                 op.kind = OP_MBCONV

@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU6, DT_BF16, DT_F32, YoloConvDesc, YoloMbconvDesc,
                    check, load)
 
-__all__ = ["stream_ptr", "pack_input", "conv2d", "conv2d_pick", "stem", "resunit", "resunit_supported", "resunit_form", "maxpool", "spp", "dwconv3x3", "dwconv", "se", "se_workspace_bytes", "mbconv", "mbconv_supported", "pack_mbconv", "conv3x3_pool", "conv3x3_pool_supported", "conv2d_splitk", "conv2d_splitk_plan", "decode", "head_decode", "head_decode_supported",
+__all__ = ["stream_ptr", "pack_input", "conv2d", "conv2d_pick", "stem", "resunit", "resunit_supported", "resunit_form", "maxpool", "spp", "dwconv3x3", "dwconv", "se", "se_workspace_bytes", "mbconv", "mbconv_supported", "mbconv_form", "pack_mbconv", "conv3x3_pool", "conv3x3_pool_supported", "conv2d_splitk", "conv2d_splitk_plan", "decode", "head_decode", "head_decode_supported",
            "nms_merge", "pack_conv_weight", "roundup", "run_ops"]
 
 
@@ -240,12 +240,28 @@ def mbconv_supported(cin: int, hidden: int, cout: int, stride: int) -> bool:
     return bool(load().yolo_mbconv_supported(cin, hidden, cout, stride))
 
 
-def pack_mbconv(w_exp, b_exp, w_dw, b_dw, w_proj, b_proj):
+def mbconv_form(cin: int, hidden: int, cout: int, stride: int) -> int:
+    """0: not covered; 1: whole hidden tile in LDS (csrc/conv_mbconv.hip); 2: hidden dimension streamed in chunks of 64
+    (csrc/conv_mbwide.hip, the blocks with 64..160 input channels).  The two forms read different weight images."""
+    return int(load().yolo_mbconv_supported(cin, hidden, cout, stride))
+
+
+def pack_mbconv(w_exp, b_exp, w_dw, b_dw, w_proj, b_proj, stride: int = 1):
     """Folded weights of one inverted-residual block -> the images yolo_mbconv_fwd reads (host tensors).
     w_exp [hidden,cin,1,1] or None, w_dw [hidden,1,3,3], w_proj [cout,hidden,1,1]; biases f32.
     Returns (we bf16 [ce,48] | None, be f32 [ce] | None, wd f32 [9,ce], bd f32 [ce], wp bf16 [cout_pad,dstride/2],
-    bp f32 [cout_pad])."""
+    bp f32 [cout_pad]); for the wide form (mbconv_form() == 2, hidden a multiple of 64) the plain matrices:
+    (we bf16 [hidden,cin], be f32 [hidden], wd f32 [9,hidden], bd f32 [hidden], wp bf16 [cout_pad,hidden], bp f32 [cout_pad])."""
     hidden, cout = w_dw.shape[0], w_proj.shape[0]
+    if w_exp is not None and mbconv_form(w_exp.shape[1], hidden, cout, stride) == 2:
+        cop = roundup(cout, 16)
+        wp = torch.zeros((cop, hidden), dtype=torch.float32)
+        wp[:cout] = w_proj.detach().float().cpu().reshape(cout, hidden)
+        bp = torch.zeros(cop, dtype=torch.float32)
+        bp[:cout] = b_proj.detach().float().cpu()
+        return (w_exp.detach().float().cpu().reshape(hidden, -1).to(torch.bfloat16).contiguous(), b_exp.detach().float().cpu().contiguous(),
+                w_dw.detach().float().cpu().reshape(hidden, 9).t().contiguous(), b_dw.detach().float().cpu().contiguous(),
+                wp.to(torch.bfloat16).contiguous(), bp)
     ce, cop = roundup(hidden, 32), roundup(cout, 16)
     dstride = load().yolo_mbconv_dstride(ce)
     we = be = None

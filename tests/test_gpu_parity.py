@@ -288,7 +288,17 @@ def test_fused_residual_unit_relu6(n, h, w, c):
     (3, 33, 41, 24, 144, 32, 2),
     (2, 16, 24, 32, 192, 32, 1),      # residual
     (1, 52, 52, 32, 192, 64, 2),
-    (4, 104, 104, 24, 144, 24, 1)])   # more tiles than workgroups: the persistent loop and its prefetch
+    (4, 104, 104, 24, 144, 24, 1),    # more tiles than workgroups: the persistent loop and its prefetch
+    # the wide form (csrc/conv_mbwide.hip: hidden dimension streamed in chunks of 64)
+    (12, 52, 52, 64, 384, 64, 1),     # 13x13 tiles (192 of them), residual
+    (13, 50, 45, 96, 192, 96, 1),     # 13x13 tiles with partial ones at both edges, three K steps
+    (70, 26, 26, 64, 128, 64, 1),     # 13x13: more tiles than workgroups
+    (2, 26, 26, 64, 128, 96, 1),      # 7x7 tiles, no residual
+    (3, 13, 13, 160, 320, 160, 1),    # 7x7, five K steps, residual
+    (2, 13, 13, 160, 192, 320, 1),    # 20 cout tiles
+    (2, 26, 26, 96, 192, 160, 2),     # stride 2
+    (1, 27, 23, 64, 192, 24, 2),      # stride 2, odd sizes, cout not a multiple of 16
+    (20, 28, 28, 96, 128, 96, 1)])    # 7x7: more tiles than workgroups
 def test_fused_inverted_residual(n, h, w, cin, hidden, cout, stride):
     """yolo_mbconv_fwd (expand 1x1 -> depthwise 3x3 -> projection 1x1 [-> add] in one launch) against fp32 torch on
     the same bf16-rounded operands (both intermediates rounded to bf16 like the stored tensors of the three-launch
@@ -311,7 +321,7 @@ def test_fused_inverted_residual(n, h, w, cin, hidden, cout, stride):
     xin[..., in_co:in_co + cin] = _nhwc(x)
     ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
     y = torch.full((n, ho, wo, out_ct), -77.0, dtype=torch.bfloat16, device=DEV)
-    packed = tuple(None if t is None else t.to(DEV) for t in K.pack_mbconv(we, be, wd, bd, wp, bp))
+    packed = tuple(None if t is None else t.to(DEV) for t in K.pack_mbconv(we, be, wd, bd, wp, bp, stride=stride))
     K.mbconv(xin, packed, y, n=n, h=h, w=w, cin=cin, hidden=hidden, cout=cout, in_view=(in_ct, in_co),
              out_view=(out_ct, out_co), stride=stride, has_res=has_res)
     torch.cuda.synchronize()
@@ -1064,8 +1074,9 @@ def test_shufflenet_units_track_the_oracle():
 
 
 def test_mobilenet_fused_blocks_match_three_launch_path(monkeypatch):
-    """Whole YOLOv3TinyMobile at 416x416, 8 images: the plan with the seven inverted-residual blocks fused
-    (yolo_mbconv_fwd, thousands of tiles per launch: persistent loops, 4 / 2 / 1 workgroups per CU) against the plan
+    """Whole YOLOv3TinyMobile at 416x416, 8 images: the plan with all seventeen inverted-residual blocks fused
+    (yolo_mbconv_fwd, thousands of tiles per launch: persistent loops, 4 / 2 / 1 workgroups per CU; the ten wide ones in the
+    chunk-streaming form) against the plan
     that runs every block as expand conv + depthwise conv + projection conv.  Same rounding points, so the decoded
     boxes and scores agree to bf16 summation-order noise."""
     from pytorch_yolo_amd import YOLOv3TinyMobile
@@ -1084,7 +1095,7 @@ def test_mobilenet_fused_blocks_match_three_launch_path(monkeypatch):
         plan = plan.subs[0] if hasattr(plan, "subs") else plan          # (sub-batch streams: every sub-plan has the same list)
         n_fused.append(sum(1 for i in range(plan.n_ops) if plan.op_array[i].kind == OP_MBCONV))
         outs.append(io.float().cpu())
-    assert n_fused == [7, 0]
+    assert n_fused == [17, 0]
     a, b = outs
     assert torch.isfinite(a).all() and a.shape == (8, 3 * (26 * 26 + 13 * 13), 85)
     xy_err = (a[..., :2] - b[..., :2]).abs().max().item()                       # pixels

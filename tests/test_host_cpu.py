@@ -174,18 +174,22 @@ def test_planner_tiny_and_mobile():
     assert plan.rows_total == 2535 and [h["stride"] for h in plan.heads] == [16.0, 32.0]
     plan = _dry_plan(YOLOv3TinyMobile().eval(), 416)
     kinds = [o.kind for o in _ops(plan)]
-    # the seven inverted-residual blocks on the 208..52 maps (hidden <= 192) are one launch each (yolo_mbconv_fwd); the ten
-    # wider ones keep three launches
+    # all seventeen inverted-residual blocks are one launch each (yolo_mbconv_fwd): the seven on the 208..52 maps (hidden <= 192)
+    # with their hidden tile in LDS, the ten wide ones on the 26 / 13 maps with the hidden dimension streamed (round 4)
     mb = [o for o in _ops(plan) if o.kind == OP_MBCONV]
     assert [(o.conv.cin, o.kpad_pre, o.conv.cout, o.conv.stride, o.conv.h, bool(o.w_pre), o.conv.res_c_total) for o in mb] == [
         (32, 32, 16, 1, 208, False, 0), (16, 96, 24, 2, 208, True, 0), (24, 144, 24, 1, 104, True, 1), (24, 144, 32, 2, 104, True, 0),
-        (32, 192, 32, 1, 52, True, 1), (32, 192, 32, 1, 52, True, 1), (32, 192, 64, 2, 52, True, 0)]
+        (32, 192, 32, 1, 52, True, 1), (32, 192, 32, 1, 52, True, 1), (32, 192, 64, 2, 52, True, 0),
+        (64, 384, 64, 1, 26, True, 1), (64, 384, 64, 1, 26, True, 1), (64, 384, 64, 1, 26, True, 1), (64, 384, 96, 1, 26, True, 0),
+        (96, 576, 96, 1, 26, True, 1), (96, 576, 96, 1, 26, True, 1), (96, 576, 160, 2, 26, True, 0),
+        (160, 960, 160, 1, 13, True, 1), (160, 960, 160, 1, 13, True, 1), (160, 960, 320, 1, 13, True, 0)]
+    assert [K.mbconv_form(o.conv.cin, o.kpad_pre, o.conv.cout, o.conv.stride) for o in mb] == [1] * 7 + [2] * 10
     assert all(o.y != o.x and o.w_dw and o.bias_dw for o in mb)
     # the stride-2 first layer reads the NCHW f32 batch itself (yolo_conv1_nchw_f32_fwd, stride-2 form)
     first = _ops(plan)[0]
     assert plan.fused_input and first.kind == OP_CONV1_NCHW and (first.conv.stride, first.conv.cout, first.conv.ho) == (2, 32, 208)
-    assert kinds.count(OP_DWCONV) == 10 and kinds.count(OP_CONV) == 24 and kinds.count(OP_HEAD_DECODE) == 2
-    assert sum(1 for o in _ops(plan) if o.kind == OP_CONV and o.residual) == 7           # MobileNetV2 identity shortcuts of the wide blocks
+    assert kinds.count(OP_DWCONV) == 0 and kinds.count(OP_CONV) == 4 and kinds.count(OP_HEAD_DECODE) == 2
+    assert sum(1 for o in _ops(plan) if o.kind == OP_CONV and o.residual) == 0           # the identity shortcuts are inside the fused blocks
 
 
 @pytest.mark.parametrize("family,bs,hw,precision", [("tiny", 32, 416, "bf16"), ("tiny", 4, 416, "fp32"), ("mobile", 16, 416, "bf16"),
@@ -271,12 +275,15 @@ def test_every_launch_stays_inside_the_plans_allocations(family, bs, hw, precisi
             inside(op.x, m_in * d.in_c_total * 2, tag + " x")
             inside(op.y, m_out * d.out_c_total * 2, tag + " y")
             ce = K.roundup(op.kpad_pre, 32)
-            inside(op.w, K.roundup(d.cout, 16) * (_lib.load().yolo_mbconv_dstride(ce) // 2) * 2, tag + " w proj")
+            wide = K.mbconv_form(d.cin, op.kpad_pre, d.cout, d.stride) == 2      # plain matrices, read through buffer descriptors
+            inside(op.w, K.roundup(d.cout, 16) * (ce if wide else _lib.load().yolo_mbconv_dstride(ce) // 2) * 2, tag + " w proj")
+            inside(op.bias, K.roundup(d.cout, 16) * 4, tag + " b proj")
             inside(op.w_dw, 9 * ce * 4, tag + " w dw")
             inside(op.bias_dw, ce * 4, tag + " b dw")
             if op.w_pre:
-                inside(op.w_pre, ce * 48 * 2, tag + " w expand")
+                inside(op.w_pre, ce * (d.cin if wide else 48) * 2, tag + " w expand")
                 inside(op.bias_pre, ce * 4, tag + " b expand")
+            assert not wide or (op.w_pre and op.kpad_pre % 64 == 0)
         else:
             raise AssertionError(f"{tag}: not covered by the audit")
         checked += 1
