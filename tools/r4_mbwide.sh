@@ -6,10 +6,8 @@ timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "fus
 rc=$?; tail -5 gpurun_out/mbw_tests.log
 [ $rc -ne 0 ] && exit $rc
 timeout -k 10 300 python tools/layer_profile.py --workload mobile > gpurun_out/mbw_layers.txt 2>&1 || exit 1
-YOLO_MBWIDE_NT=512 timeout -k 10 300 python tools/layer_profile.py --workload mobile > gpurun_out/mbw_layers_nt512.txt 2>&1 || exit 1
 for i in 1 2; do
   timeout -k 10 300 python bench.py --workload mobile --no-cpu-baseline --no-sustained > gpurun_out/mbw_bench_wide_$i.json 2>gpurun_out/mbw_bench_wide_$i.err || exit 1
-  YOLO_MBWIDE_NT=512 timeout -k 10 300 python bench.py --workload mobile --no-cpu-baseline --no-sustained > gpurun_out/mbw_bench_wide512_$i.json 2>gpurun_out/mbw_bench_wide512_$i.err || exit 1
   YOLO_FUSE_MBCONV=narrow timeout -k 10 300 python bench.py --workload mobile --no-cpu-baseline --no-sustained > gpurun_out/mbw_bench_narrow_$i.json 2>gpurun_out/mbw_bench_narrow_$i.err || exit 1
 done
 grep -h -o '"value": [0-9.]*' gpurun_out/mbw_bench_*.json
