@@ -139,34 +139,41 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void mb
     __syncthreads();
     // ---- B: E = relu6(X We^T + be), 0 outside the image
     if (EXPAND && !(a.debug & 2)) {
-      // A wave takes a contiguous run of 16x16 tiles in pixel-row-major order, so consecutive tiles share their 16
-      // halo pixels: the pixel fragment, the in-image test and the E row address are set up once per pixel row
-      // (a wave-uniform branch) and a tile costs ~13 instructions.  Out-of-image lanes take their "bias" from a
-      // table of -1e30, which the ReLU6 clamp turns into the zero the depthwise conv must see there.
+      // A wave takes a contiguous run of 16x16 tiles in CHANNEL-tile-major order: the weight fragment and the bias (the accumulator's
+      // start value) stay in registers over the run's pixel-row tiles, so a tile costs one 1 KB LDS read (its pixel fragment) instead
+      // of three (round 4: the phase was bound by LDS traffic and by a read -> MFMA -> pack -> write chain per tile with a scalar
+      // division in front of it).  Out-of-image pixels are zeroed after packing: the depthwise conv pads the EXPANDED map.
       const int nct = ce / 16, ntl = (HPP / 16) * nct, per = (ntl + nw - 1) / nw;
-      const int t_hi = min(ntl, (wave + 1) * per);
-      int cur_rt = -1;
-      bf16x8 xf = {};
-      char* erow = nullptr;
-      const float* bsrc = lbe;
-      for (int t = wave * per; t < t_hi; ++t) {
-        const int rt = t / nct, ct = t - rt * nct;
-        if (rt != cur_rt) {
-          cur_rt = rt;
-          const int pix = rt * 16 + c16;
-          const int iy = iy0 + pix / IW, ix = ix0 + pix % IW;
-          const bool in = pix < HP && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;
-          bsrc = (in ? lbe : lbad) + q * 4;
-          erow = pix < HP ? le + pix * estride + q * 8 : nullptr;
-          xf = *reinterpret_cast<const bf16x8*>(lx + pix * kXStride + q * 16);
-        }
-        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(lwe + (ct * 16 + c16) * kXStride + q * 16);
-        f32x4 acc = *reinterpret_cast<const f32x4*>(bsrc + ct * 16);     // the bias is the accumulator's start value
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc, 0, 0, 0);
-        bf16x4 o;                                                          // lane: pixel c16, channels ct*16 + q*4 ..+3
+      int t = wave * per;
+      const int t_hi = min(ntl, t + per);
+      if (t < t_hi) {
+        int ct = t / (HPP / 16), rt = t - ct * (HPP / 16);
+        bf16x8 wf = *reinterpret_cast<const bf16x8*>(lwe + (ct * 16 + c16) * kXStride + q * 16);
+        f32x4 bias = *reinterpret_cast<const f32x4*>(lbe + ct * 16 + q * 4);
+        bf16x8 xf = *reinterpret_cast<const bf16x8*>(lx + (rt * 16 + c16) * kXStride + q * 16);
+        for (; t < t_hi; ++t) {
+          const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, bias, 0, 0, 0);
+          const int pix = rt * 16 + c16, ct_now = ct;
+          // the next tile's operands are on their way while this one is packed
+          if (++rt == HPP / 16) rt = 0, ++ct;
+          if (t + 1 < t_hi) {
+            xf = *reinterpret_cast<const bf16x8*>(lx + (rt * 16 + c16) * kXStride + q * 16);
+            if (rt == 0) {
+              wf = *reinterpret_cast<const bf16x8*>(lwe + (ct * 16 + c16) * kXStride + q * 16);
+              bias = *reinterpret_cast<const f32x4*>(lbe + ct * 16 + q * 4);
+            }
+          }
+          const int py = pix / IW, px = pix - py * IW;
+          const int iy = iy0 + py, ix = ix0 + px;
+          const bool in = (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;
+          bf16x4 o;                                                          // lane: pixel c16, channels ct*16 + q*4 ..+3
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (bf16_t)relu6(acc[e]);
-        if (erow) *reinterpret_cast<bf16x4*>(erow + ct * 32) = o;
+          for (int e = 0; e < 4; ++e) o[e] = (bf16_t)relu6(acc[e]);
+          u32x2 ow = __builtin_bit_cast(u32x2, o);
+          ow[0] = in ? ow[0] : 0u;
+          ow[1] = in ? ow[1] : 0u;
+          if (pix < HP) *reinterpret_cast<u32x2*>(le + pix * estride + ct_now * 32 + q * 8) = ow;
+        }
       }
     }
     if (EXPAND) __syncthreads();
