@@ -8,7 +8,9 @@
  *
  * Conventions
  *  - plain pointers + sizes only; every device buffer is owned by the caller (torch tensors);
- *    the library never allocates, frees or retains device memory.
+ *    the library never allocates, frees or retains device memory.  State it does keep (none of it numerics): the process-wide
+ *    tuning knobs of yolo_set_tuning / yolo_set_launch_cus, per-device "LDS limit raised" flags, and the events / CU-masked streams
+ *    a caller creates through yolo_event_create / yolo_stream_create_cu_mask and owns until it destroys them.
  *  - asynchronous launch on the caller's hipStream_t; no internal synchronisation; graph-capturable.
  *  - return 0 on success; >0 = hipError_t from the launch; <0 = YOLO_E_* argument error.
  *    yolo_last_error() returns a thread-local message for the last non-zero return.
@@ -39,6 +41,11 @@ enum { YOLO_ACT_NONE = 0, YOLO_ACT_LEAKY01 = 1, YOLO_ACT_RELU6 = 2, YOLO_ACT_REL
 enum { YOLO_DT_BF16 = 0, YOLO_DT_F32 = 1 };
 
 YOLO_API const char* yolo_last_error(void);
+/* ABI version of this header: 2.  History: 1 -> 2 (round 5; the change itself dates from round 4): YoloOp's two former padding words
+ * are head_filter_conf / head_filter_min_wh, and a HEAD_DECODE op with y == NULL and workspace != NULL now means the FILTER form
+ * (yolo_head_decode_filter_fwd) - a caller built against version 1 that left y NULL or garbage in `workspace` on a head op would
+ * silently change behaviour, so the number moved although no struct size did (yolo_abi_sizeof cannot see such a change);
+ * YoloPipeStep / yolo_pipeline_step / yolo_event_* / yolo_pack_detections / yolo_nms_merge_compact were added. */
 YOLO_API int yolo_abi_version(void);
 /* Tuning / A-B hook (process-wide, not part of the numerics contract): overrides what the environment variables
  * YOLO_CONV_VARIANT (knob 0), YOLO_CONV_DEBUG (knob 1) and YOLO_CONV_PP (knob 2) set at load time.  Returns the old value. */

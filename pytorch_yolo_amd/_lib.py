@@ -11,6 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("YOLO_HIP_LIB") or os.path.join(_HERE, "csrc", "libyolo_hip.so")   # override: A/B runs of two builds
 
+ABI_VERSION = 2          # include/yolo_hip.h, yolo_abi_version
 ACT_NONE, ACT_LEAKY01, ACT_RELU6, ACT_RELU, ACT_SWISH = 0, 1, 2, 3, 4
 DT_BF16, DT_F32 = 0, 1
 OP_CONV, OP_MAXPOOL, OP_SPP, OP_DWCONV, OP_CONV1_NCHW, OP_RESUNIT, OP_STEM, OP_HEAD_DECODE, OP_CONV1_POOL = 1, 2, 3, 4, 5, 6, 7, 8, 9
@@ -140,8 +141,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.yolo_abi_version() != 1:
-        raise RuntimeError("libyolo_hip.so ABI version mismatch")
+    if lib.yolo_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libyolo_hip.so ABI version {lib.yolo_abi_version()} != {ABI_VERSION} of this binding: rebuild with "
+                           "`python -m pytorch_yolo_amd.build --force`")
     for which, st in enumerate((YoloConvDesc, YoloOp, YoloMbconvDesc, YoloPipeStep)):
         if lib.yolo_abi_sizeof(which) != C.sizeof(st):
             raise RuntimeError(f"libyolo_hip.so: struct {st.__name__} is {lib.yolo_abi_sizeof(which)} bytes in the library, {C.sizeof(st)} in the binding")

@@ -1,6 +1,7 @@
 // Shared device/host helpers for libyolo_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -28,6 +29,22 @@ int yolo_set_error(int code, const char* fmt, ...);
 static inline int yolo_check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return yolo_set_error((int)e, "%s: %s", what, hipGetErrorString(e));
+  return 0;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the CURRENT device's code object: a launcher raises it once per
+// (kernel, device), not once per process (one process may drive several GPUs: engine.Plan carries a device).  `done` is the
+// launcher's own bit mask of devices that have it (function-local static per kernel instantiation); setting the attribute twice
+// from two threads is harmless.
+static inline int yolo_max_dyn_lds(const void* fn, int bytes, std::atomic<uint64_t>& done, const char* what) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return yolo_set_error((int)e, "%s: hipGetDevice: %s", what, hipGetErrorString(e));
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return 0;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return yolo_set_error((int)e, "%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+  done.fetch_or(bit, std::memory_order_release);
   return 0;
 }
 

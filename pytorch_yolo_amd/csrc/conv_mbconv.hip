@@ -250,13 +250,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void mb
 
 template <int S, int TH, int TW, bool EXPAND, int NT>
 int launch_nt(const MbArgs& a, size_t lds, int slots, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mbconv_kernel<S, TH, TW, EXPAND, NT>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return yolo_set_error((int)e, "mbconv: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_set{0};                 // per device (common.h)
+  if (const int rc = yolo_max_dyn_lds(reinterpret_cast<const void*>(&mbconv_kernel<S, TH, TW, EXPAND, NT>), 160 * 1024, lds_set, "mbconv")) return rc;
   const int grid = a.n_tiles < slots ? a.n_tiles : slots;
   hipLaunchKernelGGL((mbconv_kernel<S, TH, TW, EXPAND, NT>), dim3((unsigned)grid), dim3(NT), lds, s, a);
   return yolo_check_launch("yolo_mbconv_fwd");

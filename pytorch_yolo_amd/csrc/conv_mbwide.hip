@@ -299,13 +299,8 @@ int launch(MbwArgs a, hipStream_t s) {
                "mbconv (wide): cin %d cout %d does not fit the %dx%d tile form (%d bytes of LDS), or a tensor of 2 GB", a.cin, a.cout,
                TH, TW, m.total);
   a.x_bytes = (uint32_t)x_bytes;
-  static bool attr_set = false;
-  if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mbwide_kernel<S, TH, TW, NT, MC>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return yolo_set_error((int)e, "mbconv (wide): hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_set{0};                 // per device (common.h)
+  if (const int rc = yolo_max_dyn_lds(reinterpret_cast<const void*>(&mbwide_kernel<S, TH, TW, NT, MC>), 160 * 1024, lds_set, "mbconv (wide)")) return rc;
   const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
   hipLaunchKernelGGL((mbwide_kernel<S, TH, TW, NT, MC>), dim3((unsigned)grid), dim3(NT), (size_t)m.total, s, a);
   return yolo_check_launch("yolo_mbconv_fwd (wide)");
@@ -323,10 +318,16 @@ const int mbw_debug = [] {
 }  // namespace
 
 // The wide form covers: expand conv present, cin a multiple of 32 in 64..160 (stride 2: ..96), hidden a multiple of 64,
-// cout a multiple of 4 up to 320.
+// cout a multiple of 4 up to 320 - AND the 7x7-tile form (the one yolo_mbwide_launch falls back to for every map size) must fit the
+// CU: its LDS map within 160 KB and cout within its 16 * MC * 2 accumulator columns.  (stride 2, cin 96, cout in
+// (256, 320] passed the channel tests, the planner fused the block away, and the launch then refused it at run time.)
 int yolo_mbwide_supported(int cin, int hidden, int cout, int stride) {
-  return cin >= 64 && cin <= (stride == 1 ? 160 : 96) && cin % 32 == 0 && hidden % kCH == 0 && hidden >= kCH && hidden > cin && cout >= 4 &&
-         cout <= 320 && cout % 4 == 0 && (stride == 1 || stride == 2);
+  if (!(cin >= 64 && cin <= (stride == 1 ? 160 : 96) && cin % 32 == 0 && hidden % kCH == 0 && hidden >= kCH && hidden > cin && cout >= 4 &&
+        cout <= 320 && cout % 4 == 0 && (stride == 1 || stride == 2)))
+    return 0;
+  const int cop = (cout + 15) / 16 * 16;
+  const int total = stride == 2 ? lds_map<2, 7, 7>(cin, cop).total : lds_map<1, 7, 7>(cin, cop).total;
+  return total <= 160 * 1024 && cop <= 16 * 10 * 2;
 }
 
 int yolo_mbwide_launch(const void* x, const void* w_exp, const float* b_exp, const float* w_dw, const float* b_dw, const void* w_proj,
@@ -360,7 +361,7 @@ int yolo_mbwide_launch(const void* x, const void* w_exp, const float* b_exp, con
   // 13x13 tiles (a quarter of a 26x26 map: 42 % halo instead of 127 %, a quarter of the weight passes) while they give every
   // CU a tile and the block is narrow enough for their LDS / accumulator budget
   const long t13 = (long)d.n * ((a.ho + 12) / 13) * ((a.wo + 12) / 13);
-  if (d.cin <= 96 && a.cop <= 128 && (t13 >= 192 || mbw_form == 1) && mbw_form != 2)
+  if (d.cin <= 96 && a.cop <= 128 && (t13 >= 192 || mbw_form == 1) && mbw_form != 2 && lds_map<1, 13, 13>(a.cin, a.cop).total <= 160 * 1024)
     return launch<1, 13, 13, 512, 4>(a, st);
   return launch<1, 7, 7, 512, 10>(a, st);
 }

@@ -286,13 +286,8 @@ __global__ __launch_bounds__(256) void conv1_s2_nchw_kernel(const ConvArgs a, co
 template <int CIN, int COUT, bool POOL>
 int launch_small_p(const ConvArgs& a, hipStream_t s) {
   constexpr int lds = ((18 * 18 * (CIN * 2 + (CIN == 32 ? YOLO_SMALL_PAD32 : 0)) + 1023) / 1024) * 1024 + (COUT / 8) * 64 * (32 * 2 + 16);
-  static bool attr_set = false;
-  if (!attr_set) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_small_kernel<CIN, COUT, POOL>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return yolo_set_error((int)e, "conv3x3_pool: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_set{0};                 // per device (common.h)
+  if (const int rc = yolo_max_dyn_lds(reinterpret_cast<const void*>(&conv3x3_small_kernel<CIN, COUT, POOL>), lds, lds_set, "conv3x3_pool")) return rc;
   const YoloConvDesc& d = a.d;
   const long n_tiles = (long)d.n * ((d.h + 15) / 16) * ((d.w + 15) / 16);
   if (n_tiles > 0x7fffffffL) return yolo_set_error(YOLO_E_UNSUPPORTED, "conv grid too large");

@@ -328,8 +328,8 @@ extern "C" int yolo_spp_fwd(void* buf, int n, int h, int w, int c, yolo_stream_t
   const size_t lds_lines = (size_t)2 * h * w * 128;
   static const bool no_lines = getenv("YOLO_SPP_NO_LINES") != nullptr;     // A/B knob: the 8-channel form for every shape
   if (c % 64 == 0 && lds_lines <= 128 * 1024 && !no_lines) {
-    static const int attr = hipFuncSetAttribute((const void*)spp_lines_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    YOLO_REQUIRE(attr == hipSuccess, "spp: cannot raise the LDS limit");
+    static std::atomic<uint64_t> lds_set{0};               // per device (common.h)
+    if (const int rc = yolo_max_dyn_lds((const void*)spp_lines_kernel, 128 * 1024, lds_set, "spp")) return rc;
     hipLaunchKernelGGL(spp_lines_kernel, dim3((unsigned)(n * (c / 64))), dim3(512), lds_lines, (hipStream_t)s, (bf16_t*)buf, h, w, c);
     return yolo_check_launch("yolo_spp_fwd");
   }

@@ -12,7 +12,7 @@ int yolo_set_error(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* yolo_last_error(void) { return g_err; }
-extern "C" int yolo_abi_version(void) { return 1; }
+extern "C" int yolo_abi_version(void) { return 2; }   // 2 (round 5): YoloOp's former pad fields carry head_filter_conf / head_filter_min_wh, YoloPipeStep added
 extern "C" int yolo_abi_sizeof(int which) {
   switch (which) {
     case 0: return (int)sizeof(YoloConvDesc);

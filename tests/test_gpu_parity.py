@@ -44,7 +44,7 @@ def _nchw(t):      # NHWC (any dtype) on device -> NCHW f32 on host
 # ------------------------------------------------------------------------------------------------
 def test_library_loaded():
     from pytorch_yolo_amd import _lib
-    assert _lib.load().yolo_abi_version() == 1
+    assert _lib.load().yolo_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_pack_input_exact():

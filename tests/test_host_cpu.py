@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/yolo_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), "ctypes table and header disagree"
-    assert _lib.load().yolo_abi_version() == 1
+    assert _lib.load().yolo_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_struct_layout_matches_header():
@@ -184,6 +184,9 @@ def test_planner_tiny_and_mobile():
         (96, 576, 96, 1, 26, True, 1), (96, 576, 96, 1, 26, True, 1), (96, 576, 160, 2, 26, True, 0),
         (160, 960, 160, 1, 13, True, 1), (160, 960, 160, 1, 13, True, 1), (160, 960, 320, 1, 13, True, 0)]
     assert [K.mbconv_form(o.conv.cin, o.kpad_pre, o.conv.cout, o.conv.stride) for o in mb] == [1] * 7 + [2] * 10
+    # the wide form says "supported" only for shapes its launcher takes (stride 2, 96 -> 576 -> 320 needs 173 KB of LDS
+    # for the 7x7 tile form - the planner must leave such a block as three launches instead of fusing it into a run-time error)
+    assert K.mbconv_form(96, 576, 320, 2) == 0 and K.mbconv_form(96, 576, 256, 2) == 2 and K.mbconv_form(160, 960, 320, 1) == 2
     assert all(o.y != o.x and o.w_dw and o.bias_dw for o in mb)
     # the stride-2 first layer reads the NCHW f32 batch itself (yolo_conv1_nchw_f32_fwd, stride-2 form)
     first = _ops(plan)[0]
