@@ -214,13 +214,22 @@ def solo_kernel_table(plan0, repeat=5):
             e1.synchronize()
             ts.append(e0.elapsed_time(e1))
         ms = statistics.median(ts)
+        # grouped by the KERNEL that runs (the name yolo_conv2d_pick reports for the shape), not by map size: the dominant kernel of
+        # SPP-640 is one kernel on three map sizes (measurement nit 12)
         if op.kind == OP_STEM:
-            label, fl = "stem (conv 3x3 3->32 + 3x3/s2 32->64, one launch)", 2.0 * d.n * d.h * d.w * 32 * 27 + 2.0 * d.n * d.ho * d.wo * 64 * 288
+            label, fl = "stem2_kernel (conv 3x3 3->32 + 3x3/s2 32->64, one launch)", 2.0 * d.n * d.h * d.w * 32 * 27 + 2.0 * d.n * d.ho * d.wo * 64 * 288
         elif op.kind == OP_RESUNIT:
-            label, fl = f"fused residual unit C={d.cout} @{d.h}x{d.w}", 2.0 * d.n * d.h * d.w * (d.cout * d.cin) * 10
-        elif op.kind in (OP_CONV, OP_CONV1_NCHW, OP_CONV1_POOL, OP_CONV_POOL, OP_HEAD_DECODE):
+            label, fl = f"fused residual unit kernels (C = {d.cout})", 2.0 * d.n * d.h * d.w * (d.cout * d.cin) * 10
+        elif op.kind == OP_HEAD_DECODE:
+            label, fl = "conv_igemm_bf16_kernel<..., DECODE> (head conv + decode + row filter)", 2.0 * d.n * d.ho * d.wo * d.cout * d.ksize * d.ksize * d.cin
+        elif op.kind == OP_CONV:
+            fam = K.conv2d_pick(d, bool(op.residual), bool(op.y_aux)).split("<")[0]
+            name = {"t20v2": "conv3x3_t20v2_kernel", "t20s2": "conv3x3s2_t20_kernel", "igemm": "conv_igemm_bf16_kernel", "stream1x1": "conv1x1_stream_kernel",
+                    "halo": "conv3x3_halo_kernel"}.get(fam, fam)
+            label, fl = f"{name} ({d.ksize}x{d.ksize}/s{d.stride})", 2.0 * d.n * d.ho * d.wo * d.cout * d.ksize * d.ksize * d.cin
+        elif op.kind in (OP_CONV1_NCHW, OP_CONV1_POOL, OP_CONV_POOL):
             fl = 2.0 * d.n * d.ho * d.wo * d.cout * d.ksize * d.ksize * d.cin
-            label = (f"conv {d.ksize}x{d.ksize}/s{d.stride} @{d.ho}x{d.wo}" + (" head+decode" if op.kind == OP_HEAD_DECODE else ""))
+            label = "first-layer / small-cin conv (+ pool) kernels (conv_small.hip)"
         else:
             label, fl = f"op kind {op.kind}", 0.0
         g = groups.setdefault(label, dict(label=label, launches=0, ms=0.0, flops=0.0))
@@ -515,6 +524,7 @@ def main():
                                    "conv1x1_stream incl. head+decode); per step: HIP-event span from the first timed list's start to the last "
                                    "lists' end / timed steps (the pipelines' lists overlap; nothing is assumed about how well)",
                          "flops_per_step": flops_step, "ms_per_step_conv": round(conv_ms_avg, 4),
+                         "floor_ms": round(max(flops_step / 1.25e15, 0.0) * 1e3, 4),      # 5.015 TFLOP at the 1.25 PFLOP/s a bare bf16 MFMA loop holds at the power cap
                          "ms_one_list_start_to_end": round(sum(list_ms) / len(list_ms), 4)},
         }
         if args.workload != "spp":
@@ -526,6 +536,10 @@ def main():
                                "traffic": traffic, "traffic_source": traffic_src,
                                "kernel": "layer launch lists of the forward (conv / pool / depthwise / fused blocks incl. head+decode); per step: HIP-event span over the timed lists / timed steps",
                                "algorithmic_bytes_per_step": abytes, "ms_per_step_layers": round(conv_ms_avg, 4),
+                               # what the list would take at the practical roofs, whichever binds (6.3 TB/s achievable HBM, 1.25 PFLOP/s at the
+                               # power cap: MI355X_MICROARCH.md) - unlike `frac` this does not FALL when a fusion removes bytes from the numerator
+                               "floor_ms": round(max(abytes / 6.3e12, flops_step / 1.25e15) * 1e3, 4),
+                               "time_over_floor": round(conv_ms_avg / (max(abytes / 6.3e12, flops_step / 1.25e15) * 1e3), 2),
                                "mfma_tflops": round(achieved, 2), "mfma_frac": round(achieved / PEAK_BF16_TFLOPS, 4)}
         if world == 1:
             # the dominant kernel family by itself, live: every launch of one sub-batch list timed alone with HIP events

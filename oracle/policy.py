@@ -38,21 +38,26 @@ def fold_state_dict(sd):
     return out
 
 
-def run_policy(forward, sd, x, *args, policy: str = "bf16", taps=None):
+def run_policy(forward, sd, x, *args, policy: str = "bf16", taps=None, select=None):
     """``forward(sd, x, *args)`` (an oracle.models forward) under a precision policy:
     'fp32' (the oracle itself), 'bf16' (the product's rounding points), 'bf16_f32stream' (bf16 operands, residual stream
-    kept in fp32).  ``taps``: optional dict filled with every intermediate tensor by block name."""
+    kept in fp32).  ``taps``: optional dict filled with every intermediate tensor by block name.
+    ``select(name) -> bool`` (bf16 policies): only the rounding points it accepts are applied - ``name`` is a conv's block prefix
+    ("down3.seq2.1", "branch1_2.conv2", ...) for its operand rounding and "<stage>.add<i>" for the stream store; everything else
+    stays fp32 (BN folded all the same).  tests/diag/drift_attribution.py uses it to split the head-logit drift by stage."""
     if policy not in ("fp32", "bf16", "bf16_f32stream"):
         raise ValueError(policy)
     real_conv = F.conv2d
+    run_sd = sd if policy == "fp32" else fold_state_dict(sd)
+    owner = {v.data_ptr(): k[:-len(".sequence.0.weight")] for k, v in run_sd.items() if k.endswith(".sequence.0.weight")} if select else {}
 
     def conv(xx, w, b=None, **kw):
-        if policy == "fp32":
+        if policy == "fp32" or (select is not None and not select(owner.get(w.data_ptr(), "?"))):
             return real_conv(xx, w, b, **kw)
         return real_conv(bf16r(xx), bf16r(w), b, **kw)
 
     def tap(name, t):
-        r = bf16r(t) if (policy == "bf16" and ".add" in name) else None     # the stream is stored as bf16, once per unit
+        r = bf16r(t) if (policy == "bf16" and ".add" in name and (select is None or select(name))) else None     # the stream is stored as bf16, once per unit
         if taps is not None:
             taps[name] = t if r is None else r
         return r
@@ -61,7 +66,7 @@ def run_policy(forward, sd, x, *args, policy: str = "bf16", taps=None):
     ob.F.conv2d = conv
     try:
         with torch.no_grad():
-            return forward(sd if policy == "fp32" else fold_state_dict(sd), x, *args)
+            return forward(run_sd, x, *args)
     finally:
         ob.F.conv2d = real_conv
         ob.set_tap(prev)

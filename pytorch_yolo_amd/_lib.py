@@ -95,6 +95,7 @@ SIGNATURES = {
     "yolo_decode_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 5 + [C.c_float, C.c_void_p,
                                   C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "yolo_head_decode_supported": (C.c_int, [C.c_int] * 3),
+    "yolo_head_decode_pick": (C.c_int, [C.POINTER(YoloConvDesc), C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]),
     "yolo_head_decode_fwd": (C.c_int, [C.c_void_p] * 3 + [C.POINTER(YoloConvDesc), C.c_void_p, C.c_int, C.c_int, C.c_float,
                                        C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "yolo_nms_workspace_bytes": (C.c_size_t, [C.c_int] * 3),

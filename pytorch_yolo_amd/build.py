@@ -28,6 +28,7 @@ SOURCES = {
     "conv_small.hip": [],
     "conv_f32.hip": ["-ffp-contract=off"],
     "conv1x1_stream.hip": [],
+    "conv_head_stream.hip": [],
     "pointwise.hip": [],
     "efficient.hip": [],
     "preprocess.hip": ["-ffp-contract=off"],
@@ -45,7 +46,8 @@ def _stale(out: str, deps) -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_common.h"),
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(CSRC, "nms_common.h"),
+               os.path.join(CSRC, "head_epilogue.h"),
                os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "yolo_hip.h"),
                os.path.abspath(__file__)]        # per-file flags live here: a flag change rebuilds too
     objs, jobs = [], []

@@ -122,6 +122,143 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const ConvArgs a
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the same kernel software-pipelined inside the workgroup, with tiles that divide the layer evenly.
+// What the form above leaves on the table on the 80x80 maps of SPP-640 (256 -> 128, 204,800 pixels per 32 images: 0.035-0.037 ms =
+// 4.2-4.4 TB/s of in + out traffic against ~5.5 reachable):
+//   * 1,600 tiles of 128 pixels over 512 persistent workgroups = 3.125 each: 64 workgroups run a fourth tile while 448 idle (78 %);
+//   * a workgroup has nothing in flight while it multiplies, stages and stores: per tile it pays an HBM round trip (DMA -> wait ->
+//     barrier) that only the CU's second workgroup can cover.
+// Here P = 80 pixels per tile (2,560 tiles = 5 per workgroup, exactly), two tile buffers per workgroup (2 x 40 KB: still two
+// workgroups per CU), and the tile two steps ahead is requested as soon as its buffer is free - in the MIDDLE of a step, behind the
+// barrier that says every wave has read its staged rows and BEFORE this step's stores are issued: vector-memory operations retire in
+// issue order, so the wait for tile j + 1 then never waits for the acknowledgement of tile j's stores (2-3 us: header note above):
+//     issue order   DMA(0) DMA(1) | DMA(2) st(0) | DMA(3) st(1) | DMA(4) st(2) ...
+//     wait for DMA(j): all but the youngest NPW (j = 0), NPW + NST (j = 1), NPW + 2 NST (j >= 2) operations of this wave
+// (NPW DMA pieces and NST stores per wave and tile; tiles beyond the last one are requested with out-of-range offsets - zeros written
+// to a buffer nobody reads - so the counts stay uniform).  Same fragment layout, MFMA order and rounding points as the form above:
+// outputs are bit-identical to it.
+template <int N, int K, int P>   // couts (128), input channels (128 / 256 / 384), pixels per tile (a multiple of 16)
+__global__ __launch_bounds__(256, 2) void conv1x1_stream2_kernel(const ConvArgs a, int n_tiles_px) {
+  constexpr int NF = N / 64, KC = K / 32, PB = P / 16;        // cout fragments per wave, 32-channel chunks, 16-pixel blocks per tile
+  constexpr int XB = KC * P * 64;                              // bytes of a pixel tile
+  constexpr int SP = N * 2 + 16;                               // staging pitch (bytes): a pixel's couts + 16 B
+  constexpr int NPW = KC * PB / 4;                             // DMA pieces per wave and tile
+  constexpr int LPR = N / 8, RPI = 64 / LPR, NST = P / (4 * RPI);   // lanes per pixel row, rows per store instruction, stores per wave and tile
+  constexpr int BUF = ((XB > P * SP ? XB : P * SP) + 1023) / 1024 * 1024;   // a tile buffer also takes the staged result of its tile
+  static_assert(N == 128 && (KC * PB) % 4 == 0 && P % (4 * RPI) == 0 && 2 * BUF <= 80 * 1024, "shape");
+  static_assert(NPW + 2 * NST <= 60, "vmcnt is a 6-bit counter");
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const YoloConvDesc& d = a.d;
+  const ActParams ap(d.act);
+  const int c16 = lane & 15, q = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const uint32_t y_pitch = (uint32_t)d.out_c_total * 2u;
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (uint32_t)a.M * y_pitch, 0x00020000);
+
+  bf16x8 wreg[NF][KC];
+  f32x4 bv[NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    const int row = wave * 16 * NF + f * 16 + c16;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) wreg[f][kc] = *reinterpret_cast<const bf16x8*>(a.w + (long)row * d.kpad + kc * 32 + q * 8);
+    bv[f] = *reinterpret_cast<const f32x4*>(a.bias + wave * 16 * NF + f * 16 + q * 4);
+  }
+  const int drow = lane >> 2, dchunk = (lane & 3) ^ swz32(lane >> 4);
+  const uint32_t x_pitch = (uint32_t)d.in_c_total * 2u;
+  const uint32_t lane_src = (uint32_t)drow * x_pitch + (uint32_t)(d.in_c_offset + dchunk * 8) * 2u;
+  const uint32_t xfrag = (uint32_t)(c16 * 64 + ((q ^ swz32(c16 >> 2)) << 4));
+  const int orow = lane / LPR, ocol = lane % LPR;
+
+  // tile j of this workgroup = blockIdx.x + j * gridDim.x; beyond the layer: every piece out of range
+  auto issue_tile = [&](int j) {
+    const long t = (long)blockIdx.x + (long)j * gridDim.x;
+    const long p0 = t * P;
+    char* const buf = smem + (j & 1) * BUF;
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int piece = i * 4 + wave, kc = piece / PB, pb = piece - kc * PB;
+      const long px = p0 + pb * 16 + drow;
+      const uint32_t vo = (t < n_tiles_px && px < a.M) ? (uint32_t)(p0 + pb * 16) * x_pitch + lane_src : kOobOffset;
+      lds_dma16s(rx, buf + piece * 1024, vo, (uint32_t)kc * 64u);
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::: "memory");                       // the stores / DMAs that follow stay behind these (counted waits)
+#endif
+  };
+
+  const int nt = ((int)blockIdx.x < n_tiles_px) ? (n_tiles_px - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  issue_tile(0);
+  issue_tile(1);
+  for (int j = 0; j < nt; ++j) {
+    const long p0 = ((long)blockIdx.x + (long)j * gridDim.x) * P;
+    char* const buf = smem + (j & 1) * BUF;
+    if (j == 0) wait_vmcnt<NPW>();
+    else if (j == 1) wait_vmcnt<NPW + NST>();
+    else wait_vmcnt<NPW + 2 * NST>();
+    __builtin_amdgcn_s_barrier();                       // tile j has landed for every wave
+    f32x4 acc[NF][PB];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int b = 0; b < PB; ++b) acc[f][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+      for (int b = 0; b < PB; ++b) {
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(buf + (kc * PB + b) * 1024 + xfrag);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) acc[f][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[f][kc], xf, acc[f][b], 0, 0, 0);
+      }
+    wait_lds();
+    __builtin_amdgcn_s_barrier();                       // every wave is done with the pixel tile: stage the result over it
+    auto stage = [&](auto act) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int b = 0; b < PB; ++b) {
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (bf16_t)act(acc[f][b][e] + bv[f][e]);
+          *reinterpret_cast<bf16x4*>(buf + (b * 16 + c16) * SP + (wave * 16 * NF + f * 16 + q * 4) * 2) = o;
+        }
+    };
+    if (ap.swish) stage([](float v) { return v / (1.f + expf(-v)); });
+    else stage([&](float v) { return ap.plain(v); });
+    wait_lds();
+    __builtin_amdgcn_s_barrier();
+    u32x4 v[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) v[i] = *reinterpret_cast<const u32x4*>(buf + ((i * 4 + wave) * RPI + orow) * SP + ocol * 16);
+    wait_lds();
+    __builtin_amdgcn_s_barrier();                       // every wave has read its rows: the buffer takes the tile two steps ahead
+    issue_tile(j + 2);
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int row = (i * 4 + wave) * RPI + orow;
+      const uint32_t vo = p0 + row < a.M ? (uint32_t)(p0 + row) * y_pitch + (uint32_t)(d.out_c_offset + ocol * 8) * 2u : kOobOffset;
+      __builtin_amdgcn_raw_buffer_store_b128(v[i], ry, vo, 0, 0);       // (no SGPR soffset: conv3x3_t20.hip, epilogue note)
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::: "memory");
+#endif
+  }
+  wait_vmcnt<0>();                                       // (the two dummy tiles behind the last one are still landing in LDS)
+}
+
+template <int N, int K, int P>
+int launch_stream2(const ConvArgs& a, hipStream_t s) {
+  const int tiles = (a.M + P - 1) / P;
+  const int grid = tiles < 512 ? tiles : 512;        // two persistent workgroups per CU
+  if (pick_only("stream1x1p<%d couts,K %d,%d px> grid %d", N, K, P, grid)) return 0;
+  hipLaunchKernelGGL((conv1x1_stream2_kernel<N, K, P>), dim3((unsigned)grid), dim3(256), 0, s, a, tiles);
+  return yolo_check_launch("yolo_conv2d_fwd(1x1 stream, pipelined)");
+}
+
 template <int N, int K>
 int launch_stream(const ConvArgs& a, hipStream_t s) {
   const int tiles = (a.M + 127) / 128;
@@ -144,6 +281,12 @@ int yolo_conv::launch_stream1x1(const ConvArgs& a, int force, hipStream_t s) {
   // 0.0412 -> 0.0322).  With apply_act's former branch chain in the staging loop the same kernel LOST to the tiled one
   // (0.0255 vs 0.0207): four waves per workgroup have nobody to hide a serial epilogue behind.
   if (!force && a.M < 40000) return 1;
+  // round 5: the pipelined form for the 128-cout layers (YOLO_CONV_DEBUG bit 33554432: the first form, for A/Bs)
+  if (!(a.debug & 33554432)) {
+    if (d.cout == 128 && d.cin == 256) return launch_stream2<128, 256, 80>(a, s);
+    if (d.cout == 128 && d.cin == 128) return launch_stream2<128, 128, 80>(a, s);
+    if (d.cout == 128 && d.cin == 384) return launch_stream2<128, 384, 48>(a, s);
+  }
   if (d.cout == 128 && d.cin == 256) return launch_stream<128, 256>(a, s);
   if (d.cout == 128 && d.cin == 128) return launch_stream<128, 128>(a, s);
   if (d.cout == 64 && d.cin == 128) return launch_stream<64, 128>(a, s);

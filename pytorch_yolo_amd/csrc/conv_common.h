@@ -332,12 +332,14 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nblk) {
 // kernel instance they would launch there and return 0 WITHOUT launching (no GPU needed).
 bool resunit_t20_applies(int c, int n, int h, int w);   // conv_resunit_t20.hip: the shipped rule of the 20-pixel-wide tile kernels
 int launch_resunit_t20(const ConvArgs& c, const bf16_t* w1, const float* b1, int kpad1, uint32_t w1_bytes, bool force, hipStream_t s);
+int& resunit_debug();              // conv_resunit.hip: YOLO_RESUNIT_DEBUG / yolo_set_tuning(3, .)
 int launch_cus();                  // compute units the coming launches may use (256, or a CU-masked stream's share)
 char* pick_buffer();
 bool pick_only(const char* fmt, ...);   // true (and the name recorded) in pick mode
 
 int launch_halo3x3(const ConvArgs& a, hipStream_t s);   // conv3x3_halo.hip; returns 1 if it does not apply
 int launch_t20_3x3(const ConvArgs& a, int force, hipStream_t s);   // conv3x3_t20.hip (20x20 output tiles); 1 if it does not apply
+int launch_head_stream(const ConvArgs& a, int force, hipStream_t s);   // conv_head_stream.hip (head conv + decode, weight-stationary, pipelined); 1 if it does not apply
 int launch_stream1x1(const ConvArgs& a, int force, hipStream_t s);   // conv1x1_stream.hip (weight-stationary 1x1 on large maps); 1 if it does not apply
 int launch_conv1_nchw(const ConvArgs& a, const float* x_nchw, int cin_real, bool pool, hipStream_t s);
 int launch_conv1_s2_nchw(const ConvArgs& a, const float* x_nchw, int cin_real, hipStream_t s);   // conv_small.hip; 1 if it does not apply

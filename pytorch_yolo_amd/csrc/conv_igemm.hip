@@ -18,6 +18,7 @@
 // hardware writes zeros.  NS-stage LDS ring, counted vmcnt, one raw s_barrier per K step.
 #include "conv_common.h"
 #include "nms_common.h"
+#include "head_epilogue.h"
 #include <stdlib.h>
 
 using namespace yolo_conv;
@@ -412,124 +413,8 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NP)) void conv_igemm_bf16
           *reinterpret_cast<f32x4*>(stg + (wm * TM + j * 32 + r32) * DP + c0) = v;
         }
     __syncthreads();
-    const HeadDecodeArgs& h = a.hd;
-    constexpr int PPW = BM / NW;                      // pixels per wave
-    constexpr int CJ = BN / 64;                       // head channel c = lane + 64 j  ->  (anchor, role k): per-lane constants
-    int c_k[CJ];
-    long c_poff[CJ], c_ioff[CJ];                      // element offsets of (anchor, k) inside one image's p / io block
-    float c_anchor[CJ];
-#pragma unroll
-    for (int j = 0; j < CJ; ++j) {
-      const int c = lane + 64 * j;
-      const int an = c / h.no, k = c - an * h.no;
-      const bool live = c < h.na * h.no;
-      c_k[j] = live ? k : -1;
-      c_poff[j] = (long)an * hw_out * h.no + k;
-      c_ioff[j] = ((long)h.io_row_offset + (long)an * hw_out) * h.no + k;
-      c_anchor[j] = live ? (k == 2 ? h.anchor_w[an] : h.anchor_h[an]) : 0.f;
-    }
-    int m = m0 + wave * PPW;
-    if (m < a.M) {
-      int b = m / hw_out, cell = m - b * hw_out;
-      int gy = cell / d.wo, gx = cell - gy * d.wo;
-      for (int i = 0; i < PPW && m < a.M; ++i, ++m) {
-        const float* const srow = stg + (wave * PPW + i) * DP;
-        float* const pimg = h.p ? h.p + ((long)b * h.na * hw_out + cell) * h.no : nullptr;
-        float* const iimg = h.io ? h.io + ((long)b * h.io_rows_total + cell) * h.no : nullptr;
-#pragma unroll
-        for (int j = 0; j < CJ; ++j) {
-          if (c_k[j] < 0) continue;
-          const float r = srow[lane + 64 * j];
-          const float v = yolo_decode_elem<false>(r, c_k[j], gx, gy, c_anchor[j], h.stride, h.no - 5);
-          if (pimg) pimg[c_poff[j]] = r;
-          if (iimg) iimg[c_ioff[j]] = v;
-          else const_cast<float*>(srow)[lane + 64 * j] = v;   // filter mode: the decoded row stays in LDS for the scan below
-        }
-        ++cell;
-        if (++gx == d.wo) {
-          gx = 0;
-          if (++gy == d.ho) {
-            gy = 0;
-            cell = 0;
-            ++b;
-          }
-        }
-      }
-    }
-    if (!h.io) {
-      // ---- filter mode: the row filter of non_max_suppression (reference utils/utils.py:212-218; csrc/nms.hip nms_filter_kernel, whose
-      // arithmetic this repeats operation for operation on the SAME decoded values) over the wave's own PPW x na rows, straight from
-      // LDS.  Two lanes per row scan half of the classes each in order and are merged in order: first maximum wins, the first NaN
-      // poisons (torch.max semantics).  Every row leaves its key (class | ~conf | io row; ~0 if it does not survive) at its place in
-      // `row_keys`, a survivor also its record (x, y, w, h, class score) in `rec`.  io itself is never stored.
-      using namespace yolo_nms;
-      __builtin_amdgcn_wave_barrier();
-      wait_lds();                                       // this wave's decoded rows are in LDS (nobody else touches them)
-      const int nc = h.no - 5, half = (nc + 1) >> 1;
-      const int m_w0 = m0 + wave * PPW, rows_w = PPW * h.na;
-      for (int base = 0; base < rows_w; base += 32) {
-        const int rl = base + (lane >> 1), seg = lane & 1;
-        const int pi = rl / h.na, an = rl - pi * h.na;
-        const int mm = m_w0 + pi;
-        const bool live = rl < rows_w && mm < a.M;
-        const float* const row = stg + (wave * PPW + (live ? pi : 0)) * DP + (live ? an : 0) * h.no;
-        const int k0 = seg * half, k1 = min(nc, k0 + half);
-        // A row with a non-finite class score is dropped whatever its maximum is (utils.py:218), so the scan needs the NaN rules of
-        // torch.max only where they cannot matter: it keeps the first maximum (strict >) and the largest |bits| of the classes seen -
-        // all of them finite <=> that is below the exponent mask.  3 + 2 VALU instructions per class, no branches.
-        bool have = k0 < k1;
-        float best = have ? row[5 + k0] : 0.f;
-        int arg = k0;
-        uint32_t amax = have ? (__float_as_uint(best) & 0x7fffffffu) : 0u;
-        auto take = [&](float v, int k) {
-          amax = max(amax, __float_as_uint(v) & 0x7fffffffu);
-          const bool t = v > best;
-          best = t ? v : best;
-          arg = t ? k : arg;
-        };
-        int k = k0 + 1;
-        for (; k + 8 <= k1; k += 8) {                    // eight LDS reads in flight, then the compares in class order
-          float v8[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v8[e] = row[5 + k + e];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) take(v8[e], k + e);
-        }
-        for (; k < k1; ++k) take(row[5 + k], k);
-        {                                               // the two halves in class order: the right one wins only with a larger maximum
-          const float ob = __shfl_xor(best, 1);
-          const int oa = __shfl_xor(arg, 1);
-          const bool oh = __shfl_xor((int)have, 1) != 0;
-          amax = max(amax, (uint32_t)__shfl_xor((int)amax, 1));
-          const bool other_is_right = seg == 0;
-          const float lb = other_is_right ? best : ob, rb = other_is_right ? ob : best;
-          const int la = other_is_right ? arg : oa, ra = other_is_right ? oa : arg;
-          const bool lh = other_is_right ? have : oh, rh = other_is_right ? oh : have;
-          const bool take_r = rh & (!lh | (rb > lb));
-          best = take_r ? rb : lb;
-          arg = take_r ? ra : la;
-        }
-        bool all_finite = amax < 0x7f800000u;
-        bool keep = false;
-        float conf = 0.f;
-        const int bimg = live ? mm / hw_out : 0;
-        const int iorow = h.io_row_offset + an * hw_out + (mm - bimg * hw_out);
-        if (live && seg == 0) {
-          conf = row[4] * best;                                                        // utils.py:213
-          const float bw = row[2], bh = row[3];
-          all_finite = all_finite && finite_f(row[0]) && finite_f(row[1]) && finite_f(bw) && finite_f(bh) && finite_f(conf);
-          keep = (conf > h.conf_thres) && (bw > h.min_wh) && (bh > h.min_wh) && all_finite;  // :216-218
-        }
-        if (live && seg == 0) {                           // one key per row (no atomics): nms_merge compacts them
-          h.row_keys[(long)bimg * h.io_rows_total + iorow] = keep ? make_key(arg, conf, iorow) : ~0ull;
-          if (keep) {
-            float* const rp = h.rec + ((long)bimg * h.io_rows_total + iorow) * kRecFloats;
-            *reinterpret_cast<f32x4*>(rp) = f32x4{row[0], row[1], row[2], row[3]};
-            rp[4] = best;
-          }
-        }
-      }
-    }
+    const HeadLanes<BN> hl = head_lanes<BN>(a.hd, lane);
+    head_decode_rows<BM / NW, BN>(a, hl, stg, DP, m0, wave, lane);      // head_epilogue.h
   } else if constexpr (LDS_EPI && MFMA16) {
     __syncthreads();
     if constexpr (SPLITK) {
@@ -750,7 +635,7 @@ extern "C" int yolo_set_launch_cus(int n_cu) {
 
 extern "C" int yolo_set_tuning(int knob, int value) {
   read_conv_env();
-  int* const slot = knob == 0 ? &conv_variant_override : knob == 1 ? &conv_debug_flags : knob == 2 ? &conv_pp_mask : nullptr;
+  int* const slot = knob == 0 ? &conv_variant_override : knob == 1 ? &conv_debug_flags : knob == 2 ? &conv_pp_mask : knob == 3 ? &resunit_debug() : nullptr;
   YOLO_REQUIRE(slot, "set_tuning: unknown knob %d", knob);
   const int old = *slot;
   *slot = value;
@@ -811,6 +696,12 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
   YOLO_SET_STAMPS(a);
   if (hd) {   // head conv with the YOLOLayer decode as its epilogue: one 64-pixel x 256-cout tile per block
     a.hd = *hd;
+    // round 5: the pipelined weight-stationary head kernel (conv_head_stream.hip) where the map gives every persistent workgroup several
+    // 32-pixel tiles; YOLO_CONV_DEBUG bit 67108864: never (A/Bs), YOLO_CONV_PP bit 4096: on every head it can compute (tests)
+    if (!(conv_debug_flags & 67108864)) {
+      const int rc = launch_head_stream(a, (conv_pp_mask & 4096) ? 1 : 0, s);
+      if (rc != 1) return rc;
+    }
     // 8 waves (2 blocks per CU -> 4 per SIMD) when cin allows 64-deep stages; bit 8192 selects the 4-wave forms
     if (d.cin % 64 == 0 && !(conv_debug_flags & 8192)) return launch_cfg<64, 256, 1, 8, 64, 2, true, false, false, true>(a, s);
     return d.cin % 32 == 0 ? launch_cfg<64, 256, 1, 4, 32, 2, true, false, false, true>(a, s)
@@ -1066,6 +957,36 @@ extern "C" int yolo_head_decode_fwd(const void* x, const void* w_packed, const f
   return conv2d_launch_ex(x, w_packed, bias, nullptr, nullptr, nullptr, &dd, &h, (hipStream_t)s);
 }
 
+// Which kernel instance and grid a head op would launch (no launch, no GPU): yolo_conv2d_pick for yolo_head_decode_fwd (filter == 0,
+// with io) / yolo_head_decode_filter_fwd (filter != 0: the compact NMS form without p).
+extern "C" int yolo_head_decode_pick(const YoloConvDesc* dp, int na, int nc, int filter, char* out, int out_len) {
+  YOLO_REQUIRE(dp && out && out_len > 0, "head_decode_pick: bad arguments");
+  YOLO_REQUIRE(yolo_head_decode_supported(dp->cout, na, nc), "head_decode_pick: cout %d != na*(5+nc)", dp->cout);
+  out[0] = 0;
+  static float dummy[16] = {0};
+  HeadDecodeArgs h;
+  h.io = filter ? nullptr : dummy;
+  h.p = nullptr;
+  h.na = na;
+  h.no = nc + 5;
+  h.io_rows_total = na * dp->ho * dp->wo;
+  h.io_row_offset = 0;
+  h.stride = 1.f;
+  for (int i = 0; i < 4; ++i) h.anchor_w[i] = h.anchor_h[i] = 1.f;
+  h.rec = filter ? dummy : nullptr;
+  h.row_keys = filter ? (unsigned long long*)dummy : nullptr;
+  h.conf_thres = 0.f, h.min_wh = 0.f;
+  YoloConvDesc dd = *dp;
+  dd.out_dtype = YOLO_DT_F32;
+  dd.out_c_total = (dp->cout + 3) & ~3;
+  dd.out_c_offset = 0;
+  yolo_conv::g_pick = out;
+  yolo_conv::g_pick_len = out_len;
+  const int rc = conv2d_launch_ex(dummy, dummy, dummy, nullptr, nullptr, nullptr, &dd, &h, nullptr);
+  yolo_conv::g_pick = nullptr;
+  return rc;
+}
+
 // Head conv + decode + the NMS row filter in one launch: io is never written (include/yolo_hip.h, the compact NMS form).
 extern "C" int yolo_head_decode_filter_fwd(const void* x, const void* w_packed, const float* bias, const YoloConvDesc* dp,
                                            const float* anchors_px, int na, int nc, float stride_px, int io_rows_total,
@@ -1082,6 +1003,7 @@ extern "C" int yolo_head_decode_filter_fwd(const void* x, const void* w_packed, 
   if (workspace_bytes < yolo_nms_compact_workspace_bytes(d.n, io_rows_total, nc))
     return yolo_set_error(YOLO_E_WORKSPACE, "head_decode_filter: workspace %zu < %zu bytes", workspace_bytes,
                           yolo_nms_compact_workspace_bytes(d.n, io_rows_total, nc));
+  YOLO_REQUIRE((size_t)d.n * io_rows_total * yolo_nms::kRecFloats * 4 < kOobOffset, "head_decode_filter: batch too large for 32-bit record offsets");
   const yolo_nms::Workspace w = yolo_nms::carve(workspace, d.n, io_rows_total, nc, true);
   HeadDecodeArgs h;
   h.io = nullptr;

@@ -572,6 +572,11 @@ int launch(const ResUnitArgs& ra, hipStream_t s) {
 
 }  // namespace
 
+int& yolo_conv::resunit_debug() {
+  static int v = getenv("YOLO_RESUNIT_DEBUG") ? atoi(getenv("YOLO_RESUNIT_DEBUG")) : 0;
+  return v;
+}
+
 extern "C" int yolo_resunit_supported(int c, int h, int w) {
   if (c != 64 && c != 128 && c != 256) return 0;
   const long tiles = (long)((h + 15) / 16) * ((w + 15) / 16);
@@ -618,8 +623,7 @@ extern "C" int yolo_resunit_fwd(const void* x, const void* w1_packed, const floa
   ra.c.steps = 0;
   ra.c.x_bytes = (uint32_t)x_bytes;
   ra.c.w_bytes = (uint32_t)w_bytes;
-  static const int dbg = getenv("YOLO_RESUNIT_DEBUG") ? atoi(getenv("YOLO_RESUNIT_DEBUG")) : 0;   // timing ablations only
-  ra.c.debug = dbg;
+  ra.c.debug = resunit_debug();      // YOLO_RESUNIT_DEBUG / yolo_set_tuning(3, .): timing ablations and A/B forms only
   ra.w1 = (const bf16_t*)w1_packed;
   ra.b1 = b1;
   ra.kpad1 = kpad1;

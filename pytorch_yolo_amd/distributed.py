@@ -129,14 +129,32 @@ def split_gathered(all_dets, all_count) -> List[Optional[torch.Tensor]]:
     return [all_dets[i, :n].clone() if n else None for i, n in enumerate(counts)]
 
 
+def _local_detections(model, x_local, conf_thres, nms_thres):
+    """(dets [bs, cap, 7], idx, count [bs]) of this rank's shard, by the path a lone ``detect()`` takes (round 5: the sharded API used to
+    run ``model(x)`` + ``nms_raw`` - two joined half-batch lists with ``io`` materialised - and so missed what ``detect()`` gained in
+    round 4): ONE whole-batch launch list + NMS behind one FFI call in the compact NMS form (engine.StreamedPlan.detect_step) where
+    the plan allows it; the outputs are the step's own buffers, complete when this returns (the NMS runs on a side stream: the
+    collectives that follow on the caller's stream must not start before it)."""
+    x = x_local.float().contiguous()
+    plan = model.plan_for(x)
+    if hasattr(plan, "detect_step") and not model.training:
+        with torch.cuda.device(x.device):
+            fast = plan.detect_step(conf_thres, nms_thres)
+            if fast is not None:
+                fast.launch(x)
+                fast.done.synchronize()
+                return fast.out
+    io, _ = model(x)
+    return nms_raw(io, conf_thres, nms_thres)
+
+
 def detect_sharded(model, x_local: torch.Tensor, conf_thres=0.5, nms_thres=0.5, group=None, gather_cap: int = 1024, total: int = None,
                    equal_shards: bool = False):
     """``detect()`` over a batch sharded by rank: returns the reference-style list for ALL images
     (global order) on every rank.  ``x_local`` is this rank's contiguous slice of the batch.
     ``total`` = the global batch size when the shards follow ``shard_bounds`` (then the shard sizes are known without an exchange),
     or ``equal_shards=True`` when every rank holds as many images as this one; with neither, the sizes are exchanged per call."""
-    io, _ = model(x_local)
-    dets, _, count = nms_raw(io, conf_thres, nms_thres)
+    dets, _, count = _local_detections(model, x_local, conf_thres, nms_thres)
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         from .utils.utils import split_detections
         return split_detections(dets, _, count)

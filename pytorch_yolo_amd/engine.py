@@ -37,6 +37,9 @@ from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SWISH, DT_BF1
 # 64 | 128 | 256 -> 6,022: profiles/r03_fuse_resunit_ab.txt).  YOLO_FUSE_RESUNIT overrides it (tuning only).
 FUSE_RESUNIT_DEFAULT = 64 | 128
 
+# launches [a, b) of the list as S depth-first passes over image sub-batches ("a-b:S,..."; "" = off): Plan._depth_first
+DEPTH_FIRST_DEFAULT = ""
+
 
 # ------------------------------------------------------------------------------------------------
 # symbolic graph
@@ -228,6 +231,7 @@ class Plan:
         self.img_size = img_size
         self._bufs: List[Buf] = []
         self._keep = []                 # packed weights / biases kept alive
+        self.depth_first, self._x_patch = [], [(0, 0)]
         self._place()
         self.fused_input = self._first_conv_reads_nchw()
         self._alloc()
@@ -775,6 +779,12 @@ class Plan:
                 d = op.conv
                 d.n, d.h, d.w, d.cin = x.n, x.h, x.w, x.c
                 ops.append(op); op_nodes.append(nd)
+        ops, op_nodes, shift = self._depth_first(ops, op_nodes)
+        if shift:
+            splitk_ops = [(i + shift(i), wb, nc) for i, wb, nc in splitk_ops]
+            for hd in self.heads:
+                if hd["op"] is not None:
+                    hd["op"] += shift(hd["op"])
         if splitk_ops:      # one fp32 workspace and one zeroed counter array per plan: the launches run in stream order
             self._splitk_ws = torch.empty((max(w for _, w, _ in splitk_ops) + 3) // 4, dtype=torch.float32, device=self.device)
             self._splitk_cnt = torch.zeros(max(c for _, _, c in splitk_ops), dtype=torch.int32, device=self.device)
@@ -783,6 +793,81 @@ class Plan:
         self.n_ops = len(ops)
         self.op_nodes = op_nodes
         self.op_array = (YoloOp * len(ops))(*ops)
+    # -- depth-first sub-batches for the first stages ---------------------------------------------------
+    # The first stages of YOLOv3-SPP at 640x640 move 105 MB per 8 images and tensor (320x320x64 bf16) and are bound by memory
+    # latency, not by the matrix pipe.  A whole-batch launch list runs them breadth-first: every launch streams 0.4-0.8 GB, so by the
+    # time a consumer launch starts, what its producer wrote has left the 256 MB Infinity Cache.  ``YOLO_DEPTH_FIRST="a-b:S,..."``
+    # replaces launches [a, b) of the list by S passes over them, pass j on images [j n / S, (j + 1) n / S): same kernels, same tiles
+    # (a tile never crosses an image), same values - bit for bit -, the producer's sub-batch output still cache-resident when the
+    # consumer reads it.  Images are independent and the order inside a pass is the list's, so every dependency is kept; buffers
+    # that share storage (``_alloc``) do so image slice by image slice.
+    def _depth_first(self, ops, op_nodes):
+        spec = os.environ.get("YOLO_DEPTH_FIRST", DEPTH_FIRST_DEFAULT if self.rec.input.n >= 16 else "")
+        self.depth_first = []
+        self._x_patch = [(0, 0)]                            # (op index, byte offset into the caller's NCHW batch) of the ops that read it
+        if not spec or spec == "0" or self.f32:
+            return ops, op_nodes, None
+        n = self.rec.input.n
+        segs = []
+        for part in spec.split(","):
+            rng, s_ = part.split(":")
+            a, b = (int(v) for v in rng.split("-"))
+            s_ = int(s_)
+            b = min(b, len(ops))
+            ok = s_ >= 2 and n % s_ == 0 and 0 <= a < b and (not segs or a >= segs[-1][1])
+            ok = ok and all(op.kind in (OP_STEM, OP_RESUNIT, OP_CONV) and op.splits < 2 and op.conv.n == n for op in ops[a:b])
+            if ok:
+                segs.append((a, b, s_))
+        if not segs:
+            return ops, op_nodes, None
+        new_ops, new_nodes, pos, growth = [], [], 0, []
+        x_patch = []
+        for a, b, s_ in segs:
+            new_ops += ops[pos:a]; new_nodes += op_nodes[pos:a]
+            for j in range(s_):
+                for i in range(a, b):
+                    sub, x_off = self._sub_op(ops[i], j, s_)
+                    if i == 0 and self.fused_input:
+                        x_patch.append((len(new_ops), x_off))
+                    new_ops.append(sub); new_nodes.append(op_nodes[i])
+            growth.append((b, (b - a) * (s_ - 1)))
+            pos = b
+            self.depth_first.append((a, b, s_))
+        new_ops += ops[pos:]; new_nodes += op_nodes[pos:]
+        if x_patch:
+            self._x_patch = x_patch
+
+        def shift(i):                                       # how far launch i of the plain list moved (launches behind a segment only)
+            return sum(g for end, g in growth if i >= end)
+        return new_ops, new_nodes, shift
+
+    def _sub_op(self, op, j, s_):
+        """Launch ``op`` restricted to images [j n / s, (j + 1) n / s): batch size and every batch-major pointer moved."""
+        sub = YoloOp.from_buffer_copy(op)
+        d = sub.conv
+        n_sub = d.n // s_
+        first = j * n_sub
+        d.n = n_sub
+        x_off = 0
+        if op.kind == OP_STEM:
+            x_off = first * self.rec.c_in * d.h * d.w * 4                      # the caller's float32 NCHW batch (patched per call)
+        else:                                               # (a fused unit's x is also its residual: the same batch-major view)
+            sub.x = op.x + first * op.conv.h * op.conv.w * op.conv.in_c_total * 2
+        up = 4 if op.conv.upsample2x else 1
+        m_out = first * op.conv.ho * op.conv.wo
+        if op.y:
+            sub.y = op.y + m_out * up * op.conv.out_c_total * 2
+        if op.residual:
+            sub.residual = op.residual + m_out * op.conv.res_c_total * 2
+        if op.y_aux:
+            sub.y_aux = op.y_aux + m_out * op.conv.aux_c_total * 2
+        return sub, x_off
+
+    def set_input_ptr(self, ptr: int):
+        """The first layer reads the caller's float32 NCHW batch itself: point its launch(es) at this call's batch."""
+        for idx, off in self._x_patch:
+            self.op_array[idx].x = ptr + off
+
     def _build_ops_f32(self):
         """fp32 mode: one plain launch per recorded layer (yolo_conv2d_f32_fwd / yolo_maxpool_f32_fwd); concat, upsample and
         residual placement are the same epilogue options as in the bf16 list, nothing else is fused."""
@@ -845,7 +930,7 @@ class Plan:
         if self.fused_input:
             if x.dtype != torch.float32 or not x.is_contiguous() or tuple(x.shape[1:]) != (self.rec.c_in, self.rec.input.h, self.rec.input.w):
                 raise RuntimeError("input must be contiguous float32 NCHW of the planned shape")
-            self.op_array[0].x = x.data_ptr()
+            self.set_input_ptr(x.data_ptr())
         elif self.f32:
             K.pack_input_f32(x, self.input_buffer)
         else:
@@ -1417,7 +1502,7 @@ class FastStep:
         pl, sp = self.pl, self.sp
         if x.dtype != torch.float32 or not x.is_contiguous() or tuple(x.shape[1:]) != self._x_shape or x.shape[0] != sp.bs:
             raise RuntimeError("input must be contiguous float32 NCHW of the planned shape")
-        pl.op_array[0].x = x.data_ptr()
+        pl.set_input_ptr(x.data_ptr())
         # (the plan may have served another caller's buffers in between, and detect() may change the threshold per call: Plan._bound
         # says what the head ops currently point at)
         if self.compact is not None:

@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import (ACT_LEAKY01, ACT_NONE, ACT_RELU6, DT_BF16, DT_F32, YoloConvDesc, YoloMbconvDesc,
                    check, load)
 
-__all__ = ["stream_ptr", "pack_input", "conv2d", "conv2d_pick", "stem", "resunit", "resunit_supported", "resunit_form", "maxpool", "spp", "dwconv3x3", "dwconv", "se", "se_workspace_bytes", "mbconv", "mbconv_supported", "mbconv_form", "pack_mbconv", "conv3x3_pool", "conv3x3_pool_supported", "conv2d_splitk", "conv2d_splitk_plan", "decode", "head_decode", "head_decode_supported",
+__all__ = ["stream_ptr", "pack_input", "conv2d", "conv2d_pick", "head_decode_pick", "stem", "resunit", "resunit_supported", "resunit_form", "maxpool", "spp", "dwconv3x3", "dwconv", "se", "se_workspace_bytes", "mbconv", "mbconv_supported", "mbconv_form", "pack_mbconv", "conv3x3_pool", "conv3x3_pool_supported", "conv2d_splitk", "conv2d_splitk_plan", "decode", "head_decode", "head_decode_supported",
            "nms_merge", "pack_conv_weight", "roundup", "run_ops"]
 
 
@@ -127,6 +127,14 @@ def conv2d_pick(desc: YoloConvDesc, has_residual=False, has_preadd=False) -> str
     """Name + grid of the kernel instance yolo_conv2d_fwd would launch for ``desc`` (no launch, works without a GPU)."""
     buf = C.create_string_buffer(256)
     check(load().yolo_conv2d_pick(C.byref(desc), int(has_residual), int(has_preadd), buf, 256), "conv2d_pick")
+    return buf.value.decode()
+
+
+def head_decode_pick(desc: YoloConvDesc, na: int, nc: int, filter: bool = False) -> str:
+    """Name + grid of the kernel instance a head op would launch (yolo_head_decode_fwd, or with ``filter`` yolo_head_decode_filter_fwd)
+    for ``desc`` (no launch, works without a GPU)."""
+    buf = C.create_string_buffer(256)
+    check(load().yolo_head_decode_pick(C.byref(desc), na, nc, int(filter), buf, 256), "head_decode_pick")
     return buf.value.decode()
 
 

@@ -195,6 +195,41 @@ def test_planner_tiny_and_mobile():
     assert sum(1 for o in _ops(plan) if o.kind == OP_CONV and o.residual) == 0           # the identity shortcuts are inside the fused blocks
 
 
+def test_depth_first_sub_batches_of_the_first_stages(monkeypatch):
+    """YOLO_DEPTH_FIRST="a-b:S,...": launches [a, b) of the list become S passes over image sub-batches (engine.Plan._depth_first) -
+    same ops, batch size n / S, every batch-major pointer moved by the sub-batch's first image; everything behind keeps its order,
+    the head ops' indices follow, and the input pointer is patched into every sub-launch that reads the caller's batch."""
+    model = YOLOv3SPP(anchors=C.SPP_ANCHORS).eval()
+    plain = _dry_plan(model, 640, bs=8)
+    monkeypatch.setenv("YOLO_DEPTH_FIRST", "0-2:4,2-5:2")
+    plan = _dry_plan(model, 640, bs=8)
+    assert plan.depth_first == [(0, 2, 4), (2, 5, 2)] and plain.depth_first == []
+    po, do = _ops(plain), _ops(plan)
+    assert len(do) == len(po) + 2 * 3 + 3 * 1
+    assert [o.kind for o in do[:8]] == [OP_STEM, OP_RESUNIT] * 4 and [o.conv.n for o in do[:8]] == [2] * 8
+    assert [o.kind for o in do[8:14]] == [OP_CONV, OP_RESUNIT, OP_RESUNIT] * 2 and [o.conv.n for o in do[8:14]] == [4] * 6
+    assert [o.kind for o in do[14:]] == [o.kind for o in po[5:]] and all(o.conv.n == 8 for o in do[14:] if o.kind == OP_CONV)
+    img = lambda o, hw, ct: o.conv.n * hw * hw * ct * 2                      # bytes of a sub-batch of an NHWC bf16 tensor
+    for j in range(4):                                                        # stem -> unit, pass j on images [2 j, 2 j + 2)
+        st, ru = do[2 * j], do[2 * j + 1]
+        assert st.y == do[0].y + j * img(st, 320, 64) and ru.x == do[1].x + j * img(ru, 320, 64) and ru.y == do[1].y + j * img(ru, 320, 64)
+        assert ru.x == st.y and st.x is None and plan._x_patch[j] == (2 * j, j * 2 * 3 * 640 * 640 * 4)
+        assert (st.w, ru.w, ru.w_pre) == (do[0].w, do[1].w, do[1].w_pre)
+    for j in range(2):
+        cv, r1, r2 = do[8 + 3 * j: 11 + 3 * j]
+        assert cv.x == do[1].y + j * img(cv, 320, 64) and cv.y == do[8].y + j * img(cv, 160, 128)
+        assert r1.x == cv.y and r2.x == r1.y and r2.y == do[10].y + j * img(r2, 160, 128)
+    assert do[14].x == do[10].y                                               # the first whole-batch launch reads all of the last unit's output
+    assert [hd["op"] for hd in plan.heads] == [hd["op"] + 9 for hd in plain.heads]
+    assert all(do[hd["op"]].kind == OP_HEAD_DECODE for hd in plan.heads)
+    assert plan.conv_flops() == plain.conv_flops()
+    plan.set_input_ptr(1 << 20)
+    assert [do[i].x for i, _ in plan._x_patch] == [(1 << 20) + off for _, off in plan._x_patch]
+    # a spec the list cannot take (a head op inside the range, a batch the sub-batch count does not divide) leaves the list alone
+    monkeypatch.setenv("YOLO_DEPTH_FIRST", "0-5:3")
+    assert _dry_plan(model, 640, bs=8).depth_first == []
+
+
 @pytest.mark.parametrize("family,bs,hw,precision", [("tiny", 32, 416, "bf16"), ("tiny", 4, 416, "fp32"), ("mobile", 16, 416, "bf16"),
                                                      ("spp", 8, 640, "bf16"), ("spp", 1, 640, "fp32")])
 def test_every_launch_stays_inside_the_plans_allocations(family, bs, hw, precision):
@@ -511,7 +546,7 @@ def test_tile_rules_pick_the_intended_kernels():
         (16, 80, 80, 256, 512, 3, 2): "igemm<256x256,4x4 waves,BK64,2 stages,16x16x32> grid 200",
         (16, 40, 40, 512, 1024, 3, 2): "igemm<128x256,2x4 waves+4 loaders,BK64,3 stages,16x16x32> grid 200",
         # memory-bound 1x1 bottlenecks at the two big maps: weight-stationary streaming kernel
-        (16, 80, 80, 256, 128, 1, 1): "stream1x1<128 couts,K 256> grid 512",
+        (16, 80, 80, 256, 128, 1, 1): "stream1x1p<128 couts,K 256,80 px> grid 512",
         (16, 160, 160, 128, 64, 1, 1): "stream1x1<64 couts,K 128> grid 512",
         # 1x1 at 40^2 / 20^2: implicit GEMM
         (16, 40, 40, 512, 256, 1, 1): "igemm<128x256,2x8 waves,BK64,3 stages,16x16x32> grid 200",
@@ -534,7 +569,8 @@ def test_tile_rules_pick_the_intended_kernels():
         (32, 80, 80, 256, 512, 3, 2): s2 % 512,
         (32, 40, 40, 512, 1024, 3, 2): "igemm<256x256,4x4 waves,BK64,2 stages,16x16x32> grid 200",     # 256 workgroups of 20x20: one per CU
         (32, 160, 160, 128, 64, 1, 1): "stream1x1<64 couts,K 128> grid 512",
-        (32, 80, 80, 256, 128, 1, 1): "stream1x1<128 couts,K 256> grid 512",
+        (32, 80, 80, 256, 128, 1, 1): "stream1x1p<128 couts,K 256,80 px> grid 512",
+        (32, 80, 80, 384, 128, 1, 1): "stream1x1p<128 couts,K 384,48 px> grid 512",      # the /8 FPN's first conv (round 5: was 128x256 tiles)
         # (M = 51,200 >= 40,000 puts this layer under the "short-K 1x1 on a big map" rule at 32 images; measured there: 0.0256 ms,
         # 128x256 / 3 stages 0.0261, 256x256 0.0234 - profiles/r03_1x1_variants_n32.txt)
         (32, 40, 40, 512, 256, 1, 1): "igemm<256x128,4x2 waves,BK32,2 stages,16x16x32> grid 400",
@@ -542,6 +578,16 @@ def test_tile_rules_pick_the_intended_kernels():
     }
     got32 = {k: _pick(*k) for k in expect32}
     assert got32 == expect32, {k: v for k, v in got32.items() if expect32[k] != v}
+    # the detection heads (head conv + decode + row filter in one launch): the pipelined weight-stationary kernel on the 80x80 and
+    # 40x40 maps (round 5), the tiled DECODE instance where K = 1024 does not fit a wave's registers or the map is a handful of tiles
+    def head(n, hw, cin, filt=True):
+        d = K.conv_desc(n=n, h=hw, w=hw, cin=cin, in_c_total=cin, in_c_offset=0, cout=255, out_c_total=256, out_c_offset=0, ksize=1,
+                        stride=1, act=_lib.ACT_LEAKY01, kpad=cin, cout_pad=256, out_dtype=_lib.DT_F32)
+        return K.head_decode_pick(d, 3, 80, filt)
+    assert head(32, 80, 256) == head(32, 80, 256, False) == "head_stream<K 256, 4 waves, 32 px> grid 512"
+    assert head(32, 40, 512) == "head_stream<K 512, 8 waves, 32 px> grid 256"
+    assert head(32, 20, 1024).startswith("igemm<64x256,1x8 waves") and head(32, 20, 1024).endswith(",decode> grid 200")
+    assert head(32, 26, 256).startswith("igemm<64x256")           # YOLOv3-tiny's heads at 32 images: 676 tiles, one or two per workgroup
     # 13x13 maps (416 input) do not tile by 20: never the t20 kernel
     assert _pick(32, 13, 13, 512, 1024, 3, 1).startswith("igemm<")
     # a bad descriptor is still rejected in pick mode
@@ -565,7 +611,7 @@ def test_tile_rules_follow_the_cu_share_of_a_partitioned_stream():
         assert _pick(16, 40, 40, 512, 1024, 3, 2) == "igemm<256x256,4x4 waves,BK64,2 stages,16x16x32> grid 100"
         assert _pick(16, 160, 160, 128, 256, 3, 2) == "t20s2<400px x 128 couts, 4 waves, parity planes> grid 512"     # 4 per CU of the share
         assert _pick(16, 20, 20, 512, 1024, 3, 1, True) == "t20v2<400px x 128 couts, 4 waves> grid 128"
-        assert _pick(16, 80, 80, 256, 128, 1, 1) == "stream1x1<128 couts,K 256> grid 512"
+        assert _pick(16, 80, 80, 256, 128, 1, 1) == "stream1x1p<128 couts,K 256,80 px> grid 512"
     finally:
         K.set_launch_cus(old)
     assert _pick(16, 20, 20, 1024, 512, 1, 1) == "igemm<128x128,2x4 waves,BK64,3 stages,16x16x32> grid 200"
