@@ -48,7 +48,7 @@ YOLO_API const char* yolo_last_error(void);
  * YoloPipeStep / yolo_pipeline_step / yolo_event_* / yolo_pack_detections / yolo_nms_merge_compact were added. */
 YOLO_API int yolo_abi_version(void);
 /* Tuning / A-B hook (process-wide, not part of the numerics contract): overrides what the environment variables
- * YOLO_CONV_VARIANT (knob 0), YOLO_CONV_DEBUG (knob 1), YOLO_CONV_PP (knob 2) and YOLO_RESUNIT_DEBUG (knob 3) set at load time.
+ * YOLO_CONV_VARIANT (knob 0), YOLO_CONV_DEBUG (knob 1), YOLO_CONV_PP (knob 2), YOLO_RESUNIT_DEBUG (knob 3) and YOLO_MBCONV_DEBUG (knob 4) set at load time.
  * Returns the old value. */
 YOLO_API int yolo_set_tuning(int knob, int value);
 
@@ -241,7 +241,7 @@ YOLO_API int yolo_decode_fwd(const float* head, int head_c_total, const float* a
  *  ignored).  yolo_head_decode_supported(): na <= 4, 5+nc <= 128; other heads use yolo_conv2d_fwd + yolo_decode_fwd. */
 YOLO_API int yolo_head_decode_supported(int cout, int na, int nc);
 /* The kernel instance + grid a head op would launch (yolo_conv2d_pick for yolo_head_decode_fwd / - filter != 0 - yolo_head_decode_filter_fwd):
- * "head_stream<K 256, 4 waves, 32 px> grid 512" (conv_head_stream.hip, round 5) or the tiled "igemm<64x256,...,decode>"; no launch, no GPU. */
+ * "igemm<64x256,1x8 waves,BK64,2 stages,32x32x16,decode> grid 3200"; no launch, no GPU. */
 YOLO_API int yolo_head_decode_pick(const YoloConvDesc* d, int na, int nc, int filter, char* out, int out_len);
 YOLO_API int yolo_head_decode_fwd(const void* x, const void* w_packed, const float* bias, const YoloConvDesc* d,
                                   const float* anchors_px, int na, int nc, float stride_px, float* io,

@@ -28,7 +28,6 @@ SOURCES = {
     "conv_small.hip": [],
     "conv_f32.hip": ["-ffp-contract=off"],
     "conv1x1_stream.hip": [],
-    "conv_head_stream.hip": [],
     "pointwise.hip": [],
     "efficient.hip": [],
     "preprocess.hip": ["-ffp-contract=off"],

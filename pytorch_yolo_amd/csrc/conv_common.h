@@ -339,7 +339,6 @@ bool pick_only(const char* fmt, ...);   // true (and the name recorded) in pick 
 
 int launch_halo3x3(const ConvArgs& a, hipStream_t s);   // conv3x3_halo.hip; returns 1 if it does not apply
 int launch_t20_3x3(const ConvArgs& a, int force, hipStream_t s);   // conv3x3_t20.hip (20x20 output tiles); 1 if it does not apply
-int launch_head_stream(const ConvArgs& a, int force, hipStream_t s);   // conv_head_stream.hip (head conv + decode, weight-stationary, pipelined); 1 if it does not apply
 int launch_stream1x1(const ConvArgs& a, int force, hipStream_t s);   // conv1x1_stream.hip (weight-stationary 1x1 on large maps); 1 if it does not apply
 int launch_conv1_nchw(const ConvArgs& a, const float* x_nchw, int cin_real, bool pool, hipStream_t s);
 int launch_conv1_s2_nchw(const ConvArgs& a, const float* x_nchw, int cin_real, hipStream_t s);   // conv_small.hip; 1 if it does not apply

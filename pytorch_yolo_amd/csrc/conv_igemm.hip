@@ -572,6 +572,8 @@ bool pick_only(const char* fmt, ...) {
 }
 }  // namespace yolo_conv
 
+int& yolo_conv_mb_debug();   // conv_mbconv.hip: YOLO_MBCONV_DEBUG / yolo_set_tuning(4, .)
+
 namespace {
 int conv_variant_override = -1;
 int conv_debug_flags = 0;   // tuning hook (YOLO_CONV_VARIANT), see yolo_conv2d_launch
@@ -635,7 +637,8 @@ extern "C" int yolo_set_launch_cus(int n_cu) {
 
 extern "C" int yolo_set_tuning(int knob, int value) {
   read_conv_env();
-  int* const slot = knob == 0 ? &conv_variant_override : knob == 1 ? &conv_debug_flags : knob == 2 ? &conv_pp_mask : knob == 3 ? &resunit_debug() : nullptr;
+  int* const slot = knob == 0 ? &conv_variant_override : knob == 1 ? &conv_debug_flags : knob == 2 ? &conv_pp_mask : knob == 3 ? &resunit_debug()
+                    : knob == 4 ? &yolo_conv_mb_debug() : nullptr;
   YOLO_REQUIRE(slot, "set_tuning: unknown knob %d", knob);
   const int old = *slot;
   *slot = value;
@@ -696,12 +699,6 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
   YOLO_SET_STAMPS(a);
   if (hd) {   // head conv with the YOLOLayer decode as its epilogue: one 64-pixel x 256-cout tile per block
     a.hd = *hd;
-    // round 5: the pipelined weight-stationary head kernel (conv_head_stream.hip) where the map gives every persistent workgroup several
-    // 32-pixel tiles; YOLO_CONV_DEBUG bit 67108864: never (A/Bs), YOLO_CONV_PP bit 4096: on every head it can compute (tests)
-    if (!(conv_debug_flags & 67108864)) {
-      const int rc = launch_head_stream(a, (conv_pp_mask & 4096) ? 1 : 0, s);
-      if (rc != 1) return rc;
-    }
     // 8 waves (2 blocks per CU -> 4 per SIMD) when cin allows 64-deep stages; bit 8192 selects the 4-wave forms
     if (d.cin % 64 == 0 && !(conv_debug_flags & 8192)) return launch_cfg<64, 256, 1, 8, 64, 2, true, false, false, true>(a, s);
     return d.cin % 32 == 0 ? launch_cfg<64, 256, 1, 4, 32, 2, true, false, false, true>(a, s)

@@ -12,6 +12,24 @@ namespace yolo_conv {
 // k = lane, lane + 64 .. of the (5 + nc)-run, so the raw logits go to p and the decoded values to io as contiguous 340-byte runs that
 // the next pixel continues.  The head tensor itself is never written.  h.io == nullptr: FILTER mode (the compact NMS form) - the
 // decoded rows stay in LDS and the wave runs the row filter of non_max_suppression on them (below).  BN = padded head channels (256).
+// All-reduce over a row of 16 lanes by row-rotate DPP (v_max / v_min with a rotated operand: no LDS crossbar, 4 instructions).
+template <int CTRL>
+__device__ __forceinline__ int dpp_row(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ float row16_max(float v) {          // (fmaxf: a NaN operand is skipped)
+  v = fmaxf(v, __builtin_bit_cast(float, dpp_row<0x128>(__builtin_bit_cast(int, v))));     // row_ror:8
+  v = fmaxf(v, __builtin_bit_cast(float, dpp_row<0x124>(__builtin_bit_cast(int, v))));     // row_ror:4
+  v = fmaxf(v, __builtin_bit_cast(float, dpp_row<0x122>(__builtin_bit_cast(int, v))));     // row_ror:2
+  v = fmaxf(v, __builtin_bit_cast(float, dpp_row<0x121>(__builtin_bit_cast(int, v))));     // row_ror:1
+  return v;
+}
+__device__ __forceinline__ int row16_min_i(int v) {
+  v = min(v, dpp_row<0x128>(v));
+  v = min(v, dpp_row<0x124>(v));
+  v = min(v, dpp_row<0x122>(v));
+  v = min(v, dpp_row<0x121>(v));
+  return v;
+}
+
 // Per-lane constants of the decode: head channel c = lane + 64 j -> (anchor, role k), and that (anchor, role)'s anchor size.  Computed
 // ONCE per workgroup (the pipelined head kernel calls head_decode_rows per 32-pixel tile: two integer divisions per channel and the
 // anchor look-up do not belong into its tile loop).
@@ -63,113 +81,135 @@ __device__ __forceinline__ void head_decode_rows(const ConvArgs& a, const HeadLa
     c_ioff[j] = ((long)h.io_row_offset + (long)an * hw_out) * h.no + k;
     c_anchor[j] = hl.anchor[j];
   }
-  int m = m0 + wave * PPW;
-  if (m < a.M) {
-    int b = m / hw_out, cell = m - b * hw_out;
-    int gy = cell / d.wo, gx = cell - gy * d.wo;
-    for (int i = 0; i < PPW && m < a.M; ++i, ++m) {
-      const float* const srow = stg + (wave * PPW + i) * DP;
-      float* const pimg = h.p ? h.p + ((long)b * h.na * hw_out + cell) * h.no : nullptr;
-      float* const iimg = h.io ? h.io + ((long)b * h.io_rows_total + cell) * h.no : nullptr;
+  if (h.io || h.p) {
+    // ---- forward(): every head value is decoded and stored (io), the raw logits too (p).  In the filter form with p only the raw
+    // logits are stored here; the rows are then filtered below.
+    int m = m0 + wave * PPW;
+    if (m < a.M) {
+      int b = m / hw_out, cell = m - b * hw_out;
+      int gy = cell / d.wo, gx = cell - gy * d.wo;
+      for (int i = 0; i < PPW && m < a.M; ++i, ++m) {
+        const float* const srow = stg + (wave * PPW + i) * DP;
+        float* const pimg = h.p ? h.p + ((long)b * h.na * hw_out + cell) * h.no : nullptr;
+        float* const iimg = h.io ? h.io + ((long)b * h.io_rows_total + cell) * h.no : nullptr;
 #pragma unroll
-      for (int j = 0; j < CJ; ++j) {
-        if (c_k[j] < 0) continue;
-        const float r = srow[lane + 64 * j];
-        const float v = yolo_decode_elem<false>(r, c_k[j], gx, gy, c_anchor[j], h.stride, h.no - 5);
-        if (pimg) pimg[c_poff[j]] = r;
-        if (iimg) iimg[c_ioff[j]] = v;
-        else const_cast<float*>(srow)[lane + 64 * j] = v;   // filter mode: the decoded row stays in LDS for the scan below
-      }
-      ++cell;
-      if (++gx == d.wo) {
-        gx = 0;
-        if (++gy == d.ho) {
-          gy = 0;
-          cell = 0;
-          ++b;
+        for (int j = 0; j < CJ; ++j) {
+          if (c_k[j] < 0) continue;
+          const float r = srow[lane + 64 * j];
+          if (pimg) pimg[c_poff[j]] = r;
+          if (iimg) iimg[c_ioff[j]] = yolo_decode_elem<false>(r, c_k[j], gx, gy, c_anchor[j], h.stride, h.no - 5);
+        }
+        ++cell;
+        if (++gx == d.wo) {
+          gx = 0;
+          if (++gy == d.ho) {
+            gy = 0;
+            cell = 0;
+            ++b;
+          }
         }
       }
     }
+    if (h.io) return;
   }
-  if (!h.io) {
-    // ---- filter mode: the row filter of non_max_suppression (reference utils/utils.py:212-218; csrc/nms.hip nms_filter_kernel, whose
-    // arithmetic this repeats operation for operation on the SAME decoded values) over the wave's own PPW x na rows, straight from
-    // LDS.  Two lanes per row scan half of the classes each in order and are merged in order: first maximum wins, the first NaN
-    // poisons (torch.max semantics).  Every row leaves its key (class | ~conf | io row; ~0 if it does not survive) at its place in
-    // `row_keys`, a survivor also its record (x, y, w, h, class score) in `rec`.  io itself is never stored.
-    using namespace yolo_nms;
-    const uint32_t n_slots = (uint32_t)d.n * (uint32_t)h.io_rows_total;
-    const __amdgpu_buffer_rsrc_t rkeys = __builtin_amdgcn_make_buffer_rsrc((void*)h.row_keys, 0, n_slots * 8u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rrec = __builtin_amdgcn_make_buffer_rsrc((void*)h.rec, 0, n_slots * (uint32_t)(kRecFloats * 4), 0x00020000);
-    __builtin_amdgcn_wave_barrier();
-    wait_lds();                                       // this wave's decoded rows are in LDS (nobody else touches them)
-    const int nc = h.no - 5, half = (nc + 1) >> 1;
-    const int m_w0 = m0 + wave * PPW, rows_w = PPW * h.na;
-    for (int base = 0; base < rows_w; base += 32) {
-      const int rl = base + (lane >> 1), seg = lane & 1;
-      const int pi = rl / h.na, an = rl - pi * h.na;
-      const int mm = m_w0 + pi;
-      const bool live = rl < rows_w && mm < a.M;
-      const float* const row = stg + (wave * PPW + (live ? pi : 0)) * DP + (live ? an : 0) * h.no;
-      const int k0 = seg * half, k1 = min(nc, k0 + half);
-      // A row with a non-finite class score is dropped whatever its maximum is (utils.py:218), so the scan needs the NaN rules of
-      // torch.max only where they cannot matter: it keeps the first maximum (strict >) and the largest |bits| of the classes seen -
-      // all of them finite <=> that is below the exponent mask.  3 + 2 VALU instructions per class, no branches.
-      bool have = k0 < k1;
-      float best = have ? row[5 + k0] : 0.f;
-      int arg = k0;
-      uint32_t amax = have ? (__float_as_uint(best) & 0x7fffffffu) : 0u;
-      auto take = [&](float v, int k) {
-        amax = max(amax, __float_as_uint(v) & 0x7fffffffu);
-        const bool t = v > best;
-        best = t ? v : best;
-        arg = t ? k : arg;
-      };
-      int k = k0 + 1;
-      for (; k + 8 <= k1; k += 8) {                    // eight LDS reads in flight, then the compares in class order
-        float v8[8];
+  // ---- FILTER form (detect(): io is never written): the row filter of non_max_suppression (reference utils/utils.py:212-218;
+  // csrc/nms.hip nms_filter_kernel, whose arithmetic this repeats on the SAME decoded values - yolo_decode_elem<false> - so that the
+  // compact NMS form stays bit-equal to head + io + nms_filter) over the wave's own PPW x na rows.
+  // Round 5: only what can decide a row is decoded.  Rounds 3-4 decoded all na * (5 + nc) values of every pixel (exp + rcp each) and
+  // let two lanes per row scan the 80 decoded class scores one after the other: ~25 M vector instructions per 32 SPP-640 images,
+  // which - not the conv, not the stores - is what most of the 80x80 head's 0.115 ms were.  Now a row is handled by a GROUP OF 16
+  // LANES (four rows per wave and pass, class c on lane c % 16, reductions by row-rotate DPP: no LDS crossbar, no loop over classes):
+  //   1. objectness first: conf = s(obj) * best <= s(obj) (best <= 1, one fp32 product), so a row with s(obj) <= conf_thres cannot
+  //      survive whatever its classes are - a pass without a candidate row only stores its ~0 keys (a NaN objectness fails the `<=`
+  //      and takes the full path, where the finite test drops it as the reference does);
+  //   2. the maximum class LOGIT l* of the row (a sigmoid is monotone up to its rounding), then only the classes whose logit lies in
+  //      a window below l* are decoded and the reference's "first maximum of the decoded scores" is taken among them.  The window is
+  //      wide enough for every class that can tie with or exceed the decoded maximum: two scores differ by more than the decode's
+  //      error (2^-21 relative) once the logits are 0.25 apart below l* = 12 (s'(12) = 6e-6 per unit), and above that everything
+  //      from logit 11 up is decoded (saturated scores do tie: s(17) = s(30) = 1.0f, and the FIRST of them wins as in torch.max);
+  //   3. a NaN class logit anywhere drops the row (utils.py:218 via isfinite; +-inf logits decode to 1 / 0 and are fine), nc = 1
+  //      has the reference's constant class score 1 (yolo_layer.py:95-96);
+  //   4. box (x, y, w, h) and conf are decoded by the group's first lane, for candidates only.
+  // Every row leaves its key (class | ~conf | io row; ~0 if it does not survive) at its place in `row_keys`, a survivor also its record
+  // (x, y, w, h, class score) in `rec`.
+  using namespace yolo_nms;
+  static_assert((PPW & (PPW - 1)) == 0, "rows are numbered anchor * PPW + pixel");
+  const int nc = h.no - 5;
+  const int grp = lane >> 4, sub = lane & 15;
+  const int ni = (nc + 15) >> 4;                                           // class slots per lane (<= 8: 5 + nc <= 128)
+  // (opaque scalars + selects, as in head_lanes: an indexed read of the kernel-argument table becomes a scratch load)
+  float sw[4], sh[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v8[e] = row[5 + k + e];
+  for (int i = 0; i < 4; ++i) {
+    sw[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, h.anchor_w[i])));
+    sh[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, h.anchor_h[i])));
+  }
+  for (int r0 = 0; r0 < PPW * h.na; r0 += 4) {
+    const int rl = r0 + grp;                                                // this group's row: anchor rl / PPW, pixel rl % PPW
+    const int an = rl / PPW, pi = rl & (PPW - 1);
+    const int mm = m0 + wave * PPW + pi;
+    const bool live = an < h.na && mm < a.M;
+    const float* const row = stg + (wave * PPW + pi) * DP + (live ? an : 0) * h.no;
+    const float s_obj = yolo_decode_elem<false>(row[4], 4, 0, 0, 0.f, h.stride, nc);
+    const bool cand = live && !(s_obj <= h.conf_thres);
+    const int bimg = live ? mm / hw_out : 0;
+    const int cell = mm - bimg * hw_out;
+    const int iorow = h.io_row_offset + an * hw_out + cell;
+    const long slot = (long)bimg * h.io_rows_total + iorow;
+    if (__ballot(cand) == 0) {                                              // (wave-uniform) nothing in this pass can survive
+      if (live && sub == 0) h.row_keys[slot] = ~0ull;
+      continue;
+    }
+    float best = 1.f;                                                       // (nc == 1: the reference's constant class score)
+    int arg = 0;
+    bool cls_finite = true;
+    if (nc > 1) {
+      float l[8];
+      float lmax = -__builtin_inff();
+      bool nan_here = false;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) take(v8[e], k + e);
+      for (int i = 0; i < 8; ++i) {
+        const int c = sub + 16 * i;
+        l[i] = (i < ni && c < nc) ? row[5 + c] : -__builtin_inff();
+        nan_here |= l[i] != l[i];
+        lmax = fmaxf(lmax, l[i]);                                           // (fmaxf skips NaNs: such a row is dropped anyway)
       }
-      for (; k < k1; ++k) take(row[5 + k], k);
-      {                                               // the two halves in class order: the right one wins only with a larger maximum
-        const float ob = __shfl_xor(best, 1);
-        const int oa = __shfl_xor(arg, 1);
-        const bool oh = __shfl_xor((int)have, 1) != 0;
-        amax = max(amax, (uint32_t)__shfl_xor((int)amax, 1));
-        const bool other_is_right = seg == 0;
-        const float lb = other_is_right ? best : ob, rb = other_is_right ? ob : best;
-        const int la = other_is_right ? arg : oa, ra = other_is_right ? oa : arg;
-        const bool lh = other_is_right ? have : oh, rh = other_is_right ? oh : have;
-        const bool take_r = rh & (!lh | (rb > lb));
-        best = take_r ? rb : lb;
-        arg = take_r ? ra : la;
+      lmax = row16_max(lmax);
+      cls_finite = row16_max(nan_here ? 1.f : 0.f) == 0.f;
+      const float window = lmax > 12.f ? 11.f : lmax - 0.25f;
+      float dbest = -1.f;
+      int cbest = 1 << 20;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (i < ni && l[i] >= window) {                                      // (a lane's classes in ascending order: strict > keeps the first)
+          const float dv = yolo_decode_elem<false>(l[i], 5 + sub + 16 * i, 0, 0, 0.f, h.stride, nc);
+          if (dv > dbest) dbest = dv, cbest = sub + 16 * i;
+        }
       }
-      bool all_finite = amax < 0x7f800000u;
+      best = row16_max(dbest);
+      arg = row16_min_i(dbest == best ? cbest : (1 << 20));
+    }
+    if (sub == 0 && live) {
       bool keep = false;
       float conf = 0.f;
-      const int bimg = live ? mm / hw_out : 0;
-      const int iorow = h.io_row_offset + an * hw_out + (mm - bimg * hw_out);
-      if (live && seg == 0) {
-        conf = row[4] * best;                                                        // utils.py:213
-        const float bw = row[2], bh = row[3];
-        all_finite = all_finite && finite_f(row[0]) && finite_f(row[1]) && finite_f(bw) && finite_f(bh) && finite_f(conf);
-        keep = (conf > h.conf_thres) && (bw > h.min_wh) && (bh > h.min_wh) && all_finite;  // :216-218
+      f32x4 box = {0.f, 0.f, 0.f, 0.f};
+      if (cand) {
+        const int gy = cell / d.wo, gx = cell - gy * d.wo;
+        const float aw = an == 0 ? sw[0] : an == 1 ? sw[1] : an == 2 ? sw[2] : sw[3];
+        const float ah = an == 0 ? sh[0] : an == 1 ? sh[1] : an == 2 ? sh[2] : sh[3];
+        box[0] = yolo_decode_elem<false>(row[0], 0, gx, gy, 0.f, h.stride, nc);
+        box[1] = yolo_decode_elem<false>(row[1], 1, gx, gy, 0.f, h.stride, nc);
+        box[2] = yolo_decode_elem<false>(row[2], 2, gx, gy, aw, h.stride, nc);
+        box[3] = yolo_decode_elem<false>(row[3], 3, gx, gy, ah, h.stride, nc);
+        conf = s_obj * best;                                                                  // utils.py:213
+        const bool all_finite = cls_finite && finite_f(best) && finite_f(box[0]) && finite_f(box[1]) && finite_f(box[2]) && finite_f(box[3]) && finite_f(conf);
+        keep = (conf > h.conf_thres) && (box[2] > h.min_wh) && (box[3] > h.min_wh) && all_finite;   // :216-218
       }
-      // One key per row (no atomics: nms_merge compacts them), the record of a survivor at the row's place.  Buffer stores, issued
-      // by every lane of every pass - a lane with nothing to store gets an out-of-range offset, which the hardware drops -, so that a
-      // wave issues the SAME number of vector-memory operations for every tile: the pipelined head kernel (conv_head_stream.hip)
-      // counts them in its s_waitcnt vmcnt arithmetic.
-      {
-        const bool st_key = live && seg == 0, st_rec = st_key && keep;
-        const uint32_t slot = (uint32_t)bimg * (uint32_t)h.io_rows_total + (uint32_t)iorow;
-        const u64 key = keep ? make_key(arg, conf, iorow) : ~0ull;
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, key), rkeys, st_key ? slot * 8u : yolo_conv::kOobOffset, 0, 0);
-        const uint32_t ro = st_rec ? slot * (uint32_t)(kRecFloats * 4) : yolo_conv::kOobOffset;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{row[0], row[1], row[2], row[3]}), rrec, ro, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, best), rrec, ro, 16, 0);
+      h.row_keys[slot] = keep ? make_key(arg, conf, iorow) : ~0ull;        // one key per row (no atomics): nms_merge compacts them
+      if (keep) {
+        float* const rp = h.rec + slot * kRecFloats;
+        *reinterpret_cast<f32x4*>(rp) = box;
+        rp[4] = best;
       }
     }
   }

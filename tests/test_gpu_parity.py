@@ -302,8 +302,23 @@ def test_fused_residual_unit_relu6(n, h, w, c):
     (2, 13, 13, 160, 192, 320, 1),    # 20 cout tiles
     (2, 26, 26, 96, 192, 160, 2),     # stride 2
     (1, 27, 23, 64, 192, 24, 2),      # stride 2, odd sizes, cout not a multiple of 16
-    (20, 28, 28, 96, 128, 96, 1)])    # 7x7: more tiles than workgroups
-def test_fused_inverted_residual(n, h, w, cin, hidden, cout, stride):
+    (20, 28, 28, 96, 128, 96, 1),     # 7x7: more tiles than workgroups
+    # round 5, the row-strip form of the narrow blocks at sizes with several column segments and bands (partial last segment / band)
+    (3, 104, 104, 16, 96, 24, 2), (2, 61, 83, 32, 32, 16, 1), (2, 57, 70, 32, 192, 64, 2), (5, 52, 52, 32, 192, 32, 1)])
+@pytest.mark.parametrize("form", ["strip", "tile"])
+def test_fused_inverted_residual(n, h, w, cin, hidden, cout, stride, form):
+    from pytorch_yolo_amd import kernels as K
+    from pytorch_yolo_amd._lib import load
+    if form == "strip" and K.mbconv_form(cin, hidden, cout, stride) != 1:
+        pytest.skip("the wide blocks have one form")
+    old = load().yolo_set_tuning(4, 128 if form == "strip" else 0)    # YOLO_MBCONV_DEBUG bit 128: the row-strip form (opt-in, round 5)
+    try:
+        _check_fused_inverted_residual(n, h, w, cin, hidden, cout, stride)
+    finally:
+        load().yolo_set_tuning(4, old)
+
+
+def _check_fused_inverted_residual(n, h, w, cin, hidden, cout, stride):
     """yolo_mbconv_fwd (expand 1x1 -> depthwise 3x3 -> projection 1x1 [-> add] in one launch) against fp32 torch on
     the same bf16-rounded operands (both intermediates rounded to bf16 like the stored tensors of the three-launch
     path) and against the three-launch path itself; channel-offset views, image borders inside a tile and the
@@ -365,36 +380,15 @@ def test_fused_inverted_residual(n, h, w, cin, hidden, cout, stride):
                                                   (1, 10, 12, 64, 3, 80, "leaky"), (2, 8, 8, 72, 1, 3, "none"),
                                                   (1, 26, 26, 128, 1, 20, "none"), (2, 14, 14, 96, 1, 80, "leaky"),
                                                   (9, 20, 20, 256, 1, 80, "leaky"), (1, 37, 23, 64, 1, 3, "none")])
-@pytest.mark.parametrize("stream", [False, True])
-def test_fused_head_decode(n, h, w, cin, k, nc, act, stream):
+def test_fused_head_decode(n, h, w, cin, k, nc, act):
     """yolo_head_decode_fwd (head conv with the YOLOLayer decode as its epilogue) against the two-launch path
     (yolo_conv2d_fwd to an fp32 NHWC head + yolo_decode_fwd): p and io agree to fp32 summation-order noise, image
     boundaries inside a pixel tile, 3x3 heads (YOLOv3 / Lite head 3) and small class counts are exercised.
-    ``stream``: the pipelined weight-stationary head kernel (conv_head_stream.hip, round 5) forced onto every head it computes
-    (YOLO_CONV_PP bit 4096) - several tiles per persistent workgroup, a last tile partly beyond the tensor, workgroups without a tile."""
-    from pytorch_yolo_amd import kernels as K
-    from pytorch_yolo_amd._lib import ACT_LEAKY01, ACT_NONE, DT_F32
-    if stream and (k != 1 or cin not in (64, 128, 256, 512)):
-        pytest.skip("the streaming head kernel takes 1x1 heads with 64 / 128 / 256 / 512 input channels")
-    with _head_stream_forced(stream):
-        _check_fused_head_decode(n, h, w, cin, k, nc, act, stream)
+    (The epilogue is csrc/head_epilogue.h.)"""
+    _check_fused_head_decode(n, h, w, cin, k, nc, act)
 
 
-class _head_stream_forced:
-    def __init__(self, on):
-        self.on = on
-
-    def __enter__(self):
-        from pytorch_yolo_amd._lib import load
-        self.old = load().yolo_set_tuning(2, 4096 if self.on else 0)
-
-    def __exit__(self, *exc):
-        from pytorch_yolo_amd._lib import load
-        load().yolo_set_tuning(2, self.old)
-        return False
-
-
-def _check_fused_head_decode(n, h, w, cin, k, nc, act, stream):
+def _check_fused_head_decode(n, h, w, cin, k, nc, act):
     from pytorch_yolo_amd import kernels as K
     from pytorch_yolo_amd._lib import ACT_LEAKY01, ACT_NONE, DT_F32
     na, no = 3, nc + 5
@@ -415,13 +409,8 @@ def _check_fused_head_decode(n, h, w, cin, k, nc, act, stream):
                     out_c_offset=0, ksize=k, stride=1, act=a, kpad=kpad, cout_pad=cout_pad, out_dtype=DT_F32)
     io = torch.full((n, rows_total, no), -7.0, device=DEV)
     p = torch.full((n, na, h, w, no), -7.0, device=DEV)
-    assert K.head_decode_pick(d, na, nc).startswith("head_stream<" if stream else "igemm<")
+    assert K.head_decode_pick(d, na, nc).startswith("igemm<") and ",decode>" in K.head_decode_pick(d, na, nc)
     K.head_decode(xin, wp.to(DEV), bp.to(DEV), d, anchors, nc, stride, io, row_off, p)
-    if stream:                                               # run to run identical (tile buffers refilled two steps ahead)
-        io_b, p_b = torch.full_like(io, -7.0), torch.full_like(p, -7.0)
-        K.head_decode(xin, wp.to(DEV), bp.to(DEV), d, anchors, nc, stride, io_b, row_off, p_b)
-        torch.cuda.synchronize()
-        assert torch.equal(io, io_b) and torch.equal(p, p_b)
     head = torch.zeros(n, h, w, K.roundup(cout, 8), device=DEV)
     K.conv2d(xin, wp.to(DEV), bp.to(DEV), head, d)
     io2 = torch.full((n, rows_total, no), -7.0, device=DEV)
@@ -444,15 +433,7 @@ def _check_fused_head_decode(n, h, w, cin, k, nc, act, stream):
                                                       (1, 26, 26, 128, 1, 20, "none", 0.1), (2, 14, 14, 96, 1, 80, "leaky", 0.001),
                                                       (5, 3, 3, 64, 1, 1, "none", 0.3), (32, 2, 2, 128, 1, 80, "none", 0.01),
                                                       (9, 20, 20, 256, 1, 80, "leaky", 0.05), (3, 37, 23, 512, 1, 20, "none", 0.05)])
-@pytest.mark.parametrize("stream", [False, True])
-def test_head_decode_filter_is_the_plain_head_plus_nms(n, h, w, cin, k, nc, act, conf, stream):
-    if stream and (k != 1 or cin not in (64, 128, 256, 512)):
-        pytest.skip("the streaming head kernel takes 1x1 heads with 64 / 128 / 256 / 512 input channels")
-    with _head_stream_forced(stream):
-        _check_head_decode_filter(n, h, w, cin, k, nc, act, conf, stream)
-
-
-def _check_head_decode_filter(n, h, w, cin, k, nc, act, conf, stream):
+def test_head_decode_filter_is_the_plain_head_plus_nms(n, h, w, cin, k, nc, act, conf):
     """The compact NMS form (round 4: yolo_head_decode_filter_fwd -> yolo_nms_merge_compact; detect()
     never writes io) against the plain one (yolo_head_decode_fwd stores io, yolo_nms_merge filters and merges it) on the same
     operands: counts, kept rows and all 7 columns BIT-EQUAL - the epilogue's row filter repeats nms_filter's arithmetic on the same
@@ -492,8 +473,6 @@ def _check_head_decode_filter(n, h, w, cin, k, nc, act, conf, stream):
     # compact: the head filters its own rows, no io
     ws_b = torch.full((K.nms_compact_workspace_bytes(n, rows_total, nc),), 0xCD, dtype=torch.uint8, device=DEV)
     out_b = mk()
-    # (stream: BOTH forms run the pipelined kernel - the filter form with its counted waits, the io form with vmcnt(0))
-    assert K.head_decode_pick(d, na, nc, filter=True).startswith("head_stream<" if stream else "igemm<")
     K.head_decode_filter(xin, wp, bp, d, anchors, nc, stride, rows_total, row_off, conf, ws_b, min_wh=MIN_WH)
     K.nms_merge_compact(ws_b, n, rows_total, nc, 0.5, *out_b, max_per_class=MAX_PER_CLASS)
     torch.cuda.synchronize()
@@ -2173,7 +2152,7 @@ def test_bf16_strict_pairing_rate_on_generic_weights():
     assert min(ra, rb) >= PAIRING_FLOOR and abs(tot[0] - tot[2]) <= 0.1 * tot[0]
 
 
-PAIRING_FLOOR = 0.40      # strict pairing rate over the 32-image batch (set from the first measurement, see the test's docstring)
+PAIRING_FLOOR = 0.75      # strict pairing rate over the 32-image batch: measured 0.838 / 0.827 (profiles/r05_pairing_rate.txt); the CPU rounding model pairs 0.84 / 0.80 on the golden image
 
 
 def test_secondary_configs_at_bench_batch_sizes():

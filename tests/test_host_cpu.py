@@ -578,16 +578,13 @@ def test_tile_rules_pick_the_intended_kernels():
     }
     got32 = {k: _pick(*k) for k in expect32}
     assert got32 == expect32, {k: v for k, v in got32.items() if expect32[k] != v}
-    # the detection heads (head conv + decode + row filter in one launch): the pipelined weight-stationary kernel on the 80x80 and
-    # 40x40 maps (round 5), the tiled DECODE instance where K = 1024 does not fit a wave's registers or the map is a handful of tiles
+    # the detection heads (head conv + decode + row filter in one launch): 64-pixel x 256-cout DECODE tiles
     def head(n, hw, cin, filt=True):
         d = K.conv_desc(n=n, h=hw, w=hw, cin=cin, in_c_total=cin, in_c_offset=0, cout=255, out_c_total=256, out_c_offset=0, ksize=1,
                         stride=1, act=_lib.ACT_LEAKY01, kpad=cin, cout_pad=256, out_dtype=_lib.DT_F32)
         return K.head_decode_pick(d, 3, 80, filt)
-    assert head(32, 80, 256) == head(32, 80, 256, False) == "head_stream<K 256, 4 waves, 32 px> grid 512"
-    assert head(32, 40, 512) == "head_stream<K 512, 8 waves, 32 px> grid 256"
-    assert head(32, 20, 1024).startswith("igemm<64x256,1x8 waves") and head(32, 20, 1024).endswith(",decode> grid 200")
-    assert head(32, 26, 256).startswith("igemm<64x256")           # YOLOv3-tiny's heads at 32 images: 676 tiles, one or two per workgroup
+    assert head(32, 80, 256) == head(32, 80, 256, False) == "igemm<64x256,1x8 waves,BK64,2 stages,32x32x16,decode> grid 3200"
+    assert head(32, 20, 1024).endswith(",decode> grid 200")
     # 13x13 maps (416 input) do not tile by 20: never the t20 kernel
     assert _pick(32, 13, 13, 512, 1024, 3, 1).startswith("igemm<")
     # a bad descriptor is still rejected in pick mode
