@@ -243,7 +243,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="spp", choices=list(WORKLOADS))
     ap.add_argument("--bs", type=int, default=0, help="images per GPU (default: the BASELINE config)")
     ap.add_argument("--hw", type=int, default=0, help="square input size (default: the BASELINE config)")

@@ -487,6 +487,104 @@ def test_head_decode_filter_is_the_plain_head_plus_nms(n, h, w, cin, k, nc, act,
     print(f"[compact NMS {n}x{h}x{w} nc {nc} conf {conf}] detections per image {cnt.tolist()[:8]} - bit-equal to the plain form")
 
 
+@pytest.mark.parametrize("nc", [80, 20, 1])
+def test_head_filter_class_choice_on_crafted_logits(nc):
+    """The filter epilogue (csrc/head_epilogue.h, round 5) decodes only the classes whose LOGIT lies in a window below the row's
+    maximum and takes the reference's "first maximum of the DECODED scores" among them.  Crafted logits - an identity head conv feeds
+    bf16-exact values straight through - hold it to the plain form (head -> io -> nms_filter, which decodes and scans everything) on
+    exactly the cases that rule has to get right, bit for bit (counts, kept rows, all 7 columns):
+      saturated ties (logits 17.5 / 20 / 30 all decode to 1.0f: the FIRST wins, reference utils/utils.py:212 torch.max), exact ties,
+      near ties inside and just outside the 0.25 window, a maximum above 12 with runners-up at 11.2 / 10.9, all classes equal, huge
+      logits, an objectness of ~0 and objectness values around the threshold, w / h below min_wh.  (Non-finite logits cannot be
+      crafted this way - 0 x inf poisons the whole pixel - and are covered by test_head_decode_filter_is_the_plain_head_plus_nms.)"""
+    from pytorch_yolo_amd import kernels as K
+    from pytorch_yolo_amd._lib import ACT_NONE, DT_F32
+    from pytorch_yolo_amd.utils.utils import MAX_PER_CLASS, MIN_WH, nms_capacity
+    na, no = 3, nc + 5
+    cout = na * no
+    cin = K.roundup(cout, 32)
+    anchors = [(10., 13.), (33., 23.), (59., 119.)]
+    stride, conf = 16.0, 0.3
+    n, h, w = 2, 6, 8
+    g = torch.Generator().manual_seed(nc)
+    # logits per (image, anchor, y, x, 5 + nc), bf16-exact
+    lg = (torch.randn(n, na, h, w, no, generator=g) * 2.0 - 1.0).to(torch.bfloat16).float()
+    lg[..., 4] = 3.0                                                # objectness passes by default
+    lg[..., 2:4] = 0.5                                              # boxes wider than min_wh
+    rows = lg.view(n, na * h * w, no)
+    def put(i, cls_vals, obj=None, wh=None):
+        r = rows[0, i]
+        r[5:] = -6.0
+        for c, v in cls_vals.items():
+            if c < nc:
+                r[5 + c] = v
+        if obj is not None:
+            r[4] = obj
+        if wh is not None:
+            r[2:4] = wh
+    put(0, {3: 20.0, 7: 30.0, 11: 17.5})                           # saturated ties: class 3
+    put(1, {9: 30.0, 2: 17.5})                                     # ... class 2 (the smaller logit comes first)
+    put(2, {4: 5.0, 6: 5.0, 8: 4.96875})                           # exact tie: class 4
+    put(3, {12: 2.0, 5: 1.875, 1: 1.6875})                         # inside / outside the window: class 12
+    put(4, {15: 12.5, 0: 11.25, 17: 10.875})                       # maximum above 12
+    put(5, {c: -30.0 for c in range(nc)})                          # every score ~1e-13 and equal: class 0 (conf far below the threshold)
+    put(6, {3: 88.0, 1: 88.0})                                     # huge logits, both 1.0f: class 1
+    put(9, {2: 25.0}, obj=-88.0)                                   # objectness ~0: dropped
+    put(10, {2: 25.0}, obj=-0.84375)                               # s(obj) just below / at the threshold region
+    put(11, {2: 25.0}, obj=-0.8515625)
+    put(12, {2: 25.0}, wh=-3.0)                                    # w, h below min_wh for the small anchors
+    put(13, {0: 0.0, 1: 0.0})                                      # tie at 0.5: class 0
+    put(14, {nc - 1: 9.0})                                         # the last class (second slot of a lane when nc > 64)
+    assert torch.equal(lg.to(torch.bfloat16).float(), lg), "the crafted logits must be bf16-exact"
+    x = torch.zeros(n, cin, h, w)
+    x[:, :cout] = lg.permute(0, 1, 4, 2, 3).reshape(n, cout, h, w)
+    wt = torch.zeros(cout, cin, 1, 1)
+    wt[torch.arange(cout), torch.arange(cout), 0, 0] = 1.0
+    bias = torch.zeros(cout)
+    xin = _nhwc(x)
+    wp, bp, kpad, cout_pad = K.pack_conv_weight(wt, bias, cin)
+    wp, bp = wp.to(DEV), bp.to(DEV)
+    rows_total, row_off = na * h * w, 0
+    d = K.conv_desc(n=n, h=h, w=w, cin=cin, in_c_total=cin, in_c_offset=0, cout=cout, out_c_total=K.roundup(cout, 8),
+                    out_c_offset=0, ksize=1, stride=1, act=ACT_NONE, kpad=kpad, cout_pad=cout_pad, out_dtype=DT_F32)
+    cap = nms_capacity(rows_total, nc)
+    mk = lambda: (torch.full((n, cap, 7), -3.0, device=DEV), torch.full((n, cap), -3, dtype=torch.int32, device=DEV),
+                  torch.full((n,), -3, dtype=torch.int32, device=DEV))
+    io = torch.zeros((n, rows_total, no), device=DEV)
+    p = torch.zeros((n, na, h, w, no), device=DEV)
+    K.head_decode(xin, wp, bp, d, anchors, nc, stride, io, row_off, p)
+    torch.cuda.synchronize()
+    assert torch.equal(p.cpu(), lg), "the identity head does not pass the crafted logits through"
+    out_a = mk()
+    ws_a = torch.empty(K.nms_workspace_bytes(n, rows_total, nc), dtype=torch.uint8, device=DEV)
+    K.nms_merge(io, conf, 0.5, *out_a, ws_a, min_wh=MIN_WH, max_per_class=MAX_PER_CLASS)
+    ws_b = torch.full((K.nms_compact_workspace_bytes(n, rows_total, nc),), 0xCD, dtype=torch.uint8, device=DEV)
+    out_b = mk()
+    K.head_decode_filter(xin, wp, bp, d, anchors, nc, stride, rows_total, row_off, conf, ws_b, min_wh=MIN_WH)
+    K.nms_merge_compact(ws_b, n, rows_total, nc, 0.5, *out_b, max_per_class=MAX_PER_CLASS)
+    torch.cuda.synchronize()
+    cnt = out_a[2].cpu()
+    assert torch.equal(out_b[2].cpu(), cnt), (out_b[2].cpu().tolist(), cnt.tolist())
+    for b in range(n):
+        m = int(cnt[b])
+        assert torch.equal(out_a[1][b, :m], out_b[1][b, :m]), f"image {b}: kept rows differ"
+        assert torch.equal(out_a[0][b, :m], out_b[0][b, :m]), f"image {b}: detections differ"
+    # the crafted rows of image 0 really exercise the cases: which class a kept row got (NMS may merge rows of one class, so look
+    # at the rows through a merge-free pass: at nms_thres = 0.9999 a pivot suppresses itself only)
+    out_c = mk()
+    K.head_decode_filter(xin, wp, bp, d, anchors, nc, stride, rows_total, row_off, conf, ws_b, min_wh=MIN_WH)
+    K.nms_merge_compact(ws_b, n, rows_total, nc, 0.9999, *out_c, max_per_class=MAX_PER_CLASS)
+    torch.cuda.synchronize()
+    m0 = int(out_c[2][0])
+    kept = {int(r): int(c) for r, c in zip(out_c[1][0, :m0].cpu().tolist(), out_c[0][0, :m0, 6].cpu().tolist())}
+    if nc == 80:
+        want = {0: 3, 1: 2, 2: 4, 3: 12, 4: 15, 6: 1, 13: 0, 14: 79}
+        for r, c in want.items():
+            assert kept.get(r) == c, f"row {r}: class {kept.get(r)} instead of {c}"
+    for r in ((5, 9) if nc > 1 else (9,)):               # (nc == 1: the class score is the reference's constant 1, row 5 survives)
+        assert r not in kept, f"row {r} must be dropped"
+
+
 @pytest.mark.parametrize("n,cin,h,w", [(2, 3, 64, 64), (1, 3, 70, 106), (1, 1, 37, 50), (2, 3, 192, 352), (1, 3, 2, 2), (1, 3, 33, 17),
                                         (3, 3, 416, 416), (40, 3, 96, 96)])
 def test_fused_stem(n, cin, h, w):
