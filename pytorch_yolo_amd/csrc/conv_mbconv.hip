@@ -35,7 +35,33 @@ struct MbArgs {
   int th;               // strip form: output rows per band
   int debug;            // YOLO_MBCONV_DEBUG (timing only, results wrong): 2 no expand stage, 4 no depthwise stage, 8 no projection stage, 16 no x loads;
                         // form selection: 64 never the strip form (round 5), 1 / 32 tile-shape knobs of the tile form
+#ifdef YOLO_STAMPS
+  unsigned long long* stamps;   // diagnostic build only (tools/mbstrip_timeline.py)
+  int stamp_lds;                // byte offset of the 768-byte stamp area in LDS
+#endif
 };
+
+// Diagnostic build only (-DYOLO_STAMPS): the lead wave of every role of the strip kernel records the shader clock (s_memtime) at the
+// top of intervals 4 .. 11 (0), after the expand role's stash + fetch (1) and when the interval's work is done, in front of the
+// barrier (2): [workgroup][role 0..2][interval - 4][4 words].
+#ifdef YOLO_STAMPS
+// (into LDS, behind the kernel's own map, and copied out when the role has finished: a global store per stamp would sit in the expand
+// role's vmcnt queue between its counted loads)
+#define MB_STAMP(role, k, which)                                                                                            \
+  do {                                                                                                                      \
+    if (a.stamps && stamp_lead && (k) >= 4 && (k) < 12)                                                                     \
+      reinterpret_cast<unsigned long long*>(smem + a.stamp_lds)[((role)*8 + ((k)-4)) * 4 + (which)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define MB_STAMP_FLUSH(role)                                                                                                \
+  do {                                                                                                                      \
+    if (a.stamps && stamp_lead)                                                                                             \
+      for (int i_ = 0; i_ < 32; ++i_)                                                                                       \
+        a.stamps[((size_t)blockIdx.x * 3 + (role)) * 32 + i_] = reinterpret_cast<unsigned long long*>(smem + a.stamp_lds)[(role)*32 + i_]; \
+  } while (0)
+#else
+#define MB_STAMP(role, k, which)
+#define MB_STAMP_FLUSH(role)
+#endif
 
 constexpr int kXStride = 96;      // bytes per pixel row of the x tile / per row of W_expand: 32 bf16 + pad; rows 24 banks
                                   // apart make the 16x16x32 fragment reads (ds_read_b128) conflict-free
@@ -349,6 +375,9 @@ __global__ __launch_bounds__(1024) void mbstrip_kernel(const MbArgs a) {
   auto first_new = [&](int q) { return q == oy0 ? oy0 * S - 1 : (S == 1 ? q + 1 : 2 * q); };
   auto count_new = [&](int q) { return q == oy0 ? S + (S == 1 ? 2 : 1) : S; };      // (stride 1: rows oy0-1, oy0, oy0+1; stride 2: 2 oy0 - 1 .. + 1)
   const int c16 = lane & 15, q16 = lane >> 4;
+#ifdef YOLO_STAMPS
+  const bool stamp_lead = lane == 0 && (wave == 0 || wave == G::WE || wave == G::WE + G::WD);
+#endif
 
   if (wave < G::WE) {
     // ================= E role =================
@@ -466,6 +495,7 @@ __global__ __launch_bounds__(1024) void mbstrip_kernel(const MbArgs a) {
     // (three intervals per trip: the register set of every stash / fetch is a constant)
     auto interval = [&](auto sc, int k) {
       const int qn = oy0 + k;                            // expand for output row qn; stash the rows of qn + 1; request those of qn + 4
+      MB_STAMP(0, k, 0);
       if (k + 1 < K) stash(sc, first_new(qn + 1), count_new(qn + 1));
       else {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -473,7 +503,9 @@ __global__ __launch_bounds__(1024) void mbstrip_kernel(const MbArgs a) {
 #endif
       }
       fetch(sc, first_new(qn + 4), count_new(qn + 4));
+      MB_STAMP(0, k, 1);
       if (EXPAND && k < K && !(a.debug & 2)) expand(first_new(qn), count_new(qn));
+      MB_STAMP(0, k, 2);
       lds_barrier();
     };
     for (int k = 0; k <= K + 1; k += 3) {                // set of interval k: (k + 1) % 3
@@ -484,6 +516,7 @@ __global__ __launch_bounds__(1024) void mbstrip_kernel(const MbArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the dummy requests behind the band)
 #endif
+    MB_STAMP_FLUSH(0);
   } else if (wave < G::WE + G::WD) {
     // ================= depthwise role =================
     const int dt = tid - G::NE;
@@ -535,14 +568,17 @@ __global__ __launch_bounds__(1024) void mbstrip_kernel(const MbArgs a) {
       __syncthreads();
       lds_barrier();
       for (int k = 0; k <= K + 1; ++k) {
+        MB_STAMP(1, k, 0);
         if (k >= 1 && k <= K && on && !(a.debug & 4)) {
           const int m = (k - 1) % 3;
           if (m == 0) dw_row(std::integral_constant<int, 0>{}, k);
           else if (m == 1) dw_row(std::integral_constant<int, 1>{}, k);
           else dw_row(std::integral_constant<int, 2>{}, k);
         }
+        MB_STAMP(1, k, 2);
         lds_barrier();
       }
+      MB_STAMP_FLUSH(1);
     } else {
       const int qn = ce / 4, groups = G::NDW / qn;
       const int qd = dt % qn, grp = dt / qn;
@@ -559,6 +595,7 @@ __global__ __launch_bounds__(1024) void mbstrip_kernel(const MbArgs a) {
       lds_barrier();
       for (int k = 0; k <= K + 1; ++k) {
         const int oy = oy0 + k - 1;                      // D[k & 1] = relu6(dw3x3(E) + bd) for the TW pixels of output row oy
+        MB_STAMP(1, k, 0);
         if (k >= 1 && k <= K && dw_on && !(a.debug & 4)) {
           const int iy0 = oy * S - 1;
           char* const dbuf = ld + (k & 1) * OPS * dstride;
@@ -591,8 +628,10 @@ __global__ __launch_bounds__(1024) void mbstrip_kernel(const MbArgs a) {
             }
           }
         }
+        MB_STAMP(1, k, 2);
         lds_barrier();
       }
+      MB_STAMP_FLUSH(1);
     }
   } else {
     // ================= projection role =================
@@ -601,6 +640,7 @@ __global__ __launch_bounds__(1024) void mbstrip_kernel(const MbArgs a) {
     lds_barrier();
     for (int k = 0; k <= K + 1; ++k) {
       const int oy = oy0 + k - 2;                        // y[oy] = D[(k - 1) & 1] Wp^T + bp (+ x)
+      MB_STAMP(2, k, 0);
       if (k >= 2 && !(a.debug & 8)) {
         const char* const dbuf = ld + ((k - 1) & 1) * OPS * dstride;
         const int nct = a.cop / 16, ntl = (OPS / 16) * nct, ksteps = ce / 32;
@@ -641,8 +681,10 @@ __global__ __launch_bounds__(1024) void mbstrip_kernel(const MbArgs a) {
           }
         }
       }
+      MB_STAMP(2, k, 2);
       lds_barrier();
     }
+    MB_STAMP_FLUSH(2);
   }
 }
 
@@ -674,9 +716,17 @@ int launch_strip(const MbArgs& a0, hipStream_t s) {
   if (a.th < 8) a.th = a.ho < 8 ? a.ho : 8;
   a.tiles_y = (a.ho + a.th - 1) / a.th;
   a.n_tiles = a.n * a.tiles_x * a.tiles_y;
+#ifdef YOLO_STAMPS
+  a.stamps = getenv("YOLO_STAMP_PTR") ? (unsigned long long*)strtoull(getenv("YOLO_STAMP_PTR"), nullptr, 0) : nullptr;
+  a.stamp_lds = (int)((lds + 15) / 16 * 16);
+  if (a.stamp_lds + 768 > 160 * 1024) a.stamps = nullptr;
+  const size_t lds_launch = a.stamps ? (size_t)a.stamp_lds + 768 : lds;
+#else
+  const size_t lds_launch = lds;
+#endif
   static std::atomic<uint64_t> lds_set{0};                 // per device (common.h)
   if (const int rc = yolo_max_dyn_lds(reinterpret_cast<const void*>(&mbstrip_kernel<S, EXPAND>), 160 * 1024, lds_set, "mbconv (strip)")) return rc;
-  hipLaunchKernelGGL((mbstrip_kernel<S, EXPAND>), dim3((unsigned)a.n_tiles), dim3(1024), lds, s, a);
+  hipLaunchKernelGGL((mbstrip_kernel<S, EXPAND>), dim3((unsigned)a.n_tiles), dim3(1024), lds_launch, s, a);
   return yolo_check_launch("yolo_mbconv_fwd (strip)");
 }
 
