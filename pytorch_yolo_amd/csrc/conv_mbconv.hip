@@ -164,18 +164,45 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void mb
   const int c16 = lane & 15, q = lane >> 4;
   int tile = blockIdx.x;
   if (tile < a.n_tiles) fetch(tile);
+#if defined(__HIP_DEVICE_COMPILE__)
+  // The depthwise weights are in registers from here on, and hipcc is told so: it cannot count vector-memory operations across the
+  // tile loop, and without this a "s_waitcnt vmcnt(0)" stood in front of the first FMA of the depthwise phase of EVERY tile (the
+  // registers' loads "may" be outstanding) - draining the next tile's x loads and the y stores there.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int t = 0; t < 9; ++t) asm volatile("" : "+v"(wdr2[t][0]), "+v"(wdr2[t][1]));
+  asm volatile("" : "+v"(bdr[0]), "+v"(bdr[1]), "+v"(bdr[2]), "+v"(bdr[3]));
+#endif
   __syncthreads();
+  // Where the x tile goes to LDS (round 5, late): the first tile's here, tile i + 1's inside tile i BETWEEN the depthwise phase
+  // and the projection's stores.  It used to be the first thing of a tile, right behind the previous tile's y stores: the wait for
+  // the prefetched registers is "vmcnt(0)" (the number of younger stores is not a constant), so every tile began by waiting out the
+  // acknowledgement of those stores.  Now the youngest vector-memory operations in front of the wait are
+  // the loads themselves, one tile old.  The residual (x at the tile's centre pixels) is read into registers before the x tile is
+  // overwritten.
+  constexpr int kMaxPT = (16 + nw - 1) / nw;             // projection tiles per wave: P / 16 x cop / 16 <= 16 (launch_nt checks)
+  if (tile < a.n_tiles) {
+    stash();
+    if (tile + (int)gridDim.x < a.n_tiles && !(a.debug & 16)) fetch(tile + gridDim.x);
+    lds_barrier();
+  }
   for (; tile < a.n_tiles; tile += gridDim.x) {
     const int tx = tile % a.tiles_x, r = tile / a.tiles_x, ty = r % a.tiles_y, b = r / a.tiles_y;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
-    // ---- A: this tile's x halo (fetched during the previous tile) -> LDS; next tile's loads go out
-    stash();
-    if (tile + (int)gridDim.x < a.n_tiles && !(a.debug & 16)) fetch(tile + gridDim.x);
-    // (round 5: the barriers of the tile loop wait for LDS operations only - __syncthreads() also drains the vector-memory counter,
-    // i.e. it waited here for the next tile's x loads issued one line above, and below for the acknowledgement of the y stores;
-    // YOLO_MBCONV_DEBUG bit 256 keeps the old barriers for the A/B)
-    if (a.debug & 256) __syncthreads(); else lds_barrier();
+    // the residual values of this wave's projection tiles
+    bf16x4 xres[kMaxPT];
+    if (S == 1 && a.has_res) {                             // (a stride-2 block has no residual)
+      const int nct_p = a.cop / 16, ntl_p = (P / 16) * nct_p;
+#pragma unroll
+      for (int i = 0; i < kMaxPT; ++i) {
+        const int t = wave + i * nw;
+        const int rt = t / nct_p, ct = t - rt * nct_p;
+        const int p = rt * 16 + c16, c0 = ct * 16 + q * 4;
+        xres[i] = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+        if (t < ntl_p) xres[i] = *reinterpret_cast<const bf16x4*>(xdst + ((p / TW + 1) * IW + p % TW + 1) * xrow + c0 * 2);
+      }
+    }
     // ---- B: E = relu6(X We^T + be), 0 outside the image
     if (EXPAND && !(a.debug & 2)) {
       // A wave takes a contiguous run of 16x16 tiles in CHANNEL-tile-major order: the weight fragment and the bias (the accumulator's
@@ -250,10 +277,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void mb
       }
     }
     if (a.debug & 256) __syncthreads(); else lds_barrier();
+    // ---- the NEXT tile's x halo (fetched during this tile's first phases) -> LDS; the loads of the tile after it go out
+    if (tile + (int)gridDim.x < a.n_tiles) {
+      stash();
+      if (tile + 2 * (int)gridDim.x < a.n_tiles && !(a.debug & 16)) fetch(tile + 2 * gridDim.x);
+    }
     // ---- D: y = D Wp^T + bp (+ x)
     if (!(a.debug & 8)) {
       const int nct = a.cop / 16, ntl = (P / 16) * nct, ksteps = ce / 32;
-      for (int t = wave; t < ntl; t += nw) {
+      int ti = 0;
+      for (int t = wave; t < ntl; t += nw, ++ti) {
         const int rt = t / nct, ct = t - rt * nct;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < ksteps; ++k) {
@@ -268,8 +301,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void mb
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc[e] + bv[e];
-          if (a.has_res) {        // stride 1, cin == cout: x at the tile's centre pixel, from the LDS tile
-            const bf16x4 xv = *reinterpret_cast<const bf16x4*>(xdst + ((p / TW + 1) * IW + p % TW + 1) * xrow + c0 * 2);
+          if (S == 1 && a.has_res) {        // stride 1, cin == cout: x at the tile's centre pixel (read from the LDS tile at the top of the tile)
+            bf16x4 xv = xres[0];
+#pragma unroll
+            for (int i = 1; i < kMaxPT; ++i) xv = ti == i ? xres[i] : xv;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += (float)xv[e];
           }
@@ -283,7 +318,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void mb
         }
       }
     }
-    if (a.debug & 256) __syncthreads(); else lds_barrier();     // x tile, E and D are free for the next tile
+    if (a.debug & 256) __syncthreads(); else lds_barrier();     // E and D are free for the next tile (whose x tile is in LDS already)
   }
 }
 
@@ -754,6 +789,7 @@ int launch(const MbArgs& a0, hipStream_t s) {
   a.n_tiles = a.n * a.tiles_x * a.tiles_y;
   const size_t lds = lds_bytes<S, TH, TW, EXPAND>(a);
   YOLO_REQUIRE(lds <= 160 * 1024, "mbconv: %zu bytes of LDS needed", lds);
+  YOLO_REQUIRE((TH * TW / 16) * (a.cop / 16) <= 16, "mbconv: %d projection tiles per output tile (the kernel keeps <= 16 residual fragments)", (TH * TW / 16) * (a.cop / 16));
   // persistent workgroups; the phases of one tile (load, expand, depthwise, project) are latency chains, so a CU
   // needs more than 8 waves in flight: two 512-thread workgroups per CU when the LDS allows, else one of 1024 threads
   if (lds <= 40 * 1024) return launch_nt<S, TH, TW, EXPAND, 256>(a, lds, 1024, s);   // four per CU: phases of four tiles overlap
