@@ -304,7 +304,10 @@ def test_fused_residual_unit_relu6(n, h, w, c):
     (1, 27, 23, 64, 192, 24, 2),      # stride 2, odd sizes, cout not a multiple of 16
     (20, 28, 28, 96, 128, 96, 1),     # 7x7: more tiles than workgroups
     # round 5, the row-strip form of the narrow blocks at sizes with several column segments and bands (partial last segment / band)
-    (3, 104, 104, 16, 96, 24, 2), (2, 61, 83, 32, 32, 16, 1), (2, 57, 70, 32, 192, 64, 2), (5, 52, 52, 32, 192, 32, 1)])
+    (3, 104, 104, 16, 96, 24, 2), (2, 61, 83, 32, 32, 16, 1), (2, 57, 70, 32, 192, 64, 2), (5, 52, 52, 32, 192, 32, 1),
+    # round 5, late: residual blocks in the tile form's 256- / 512-thread instances (the residual is read into registers before the
+    # next tile's halo overwrites the x tile; a wave of the 256-thread instance owns TWO projection tiles here)
+    (3, 30, 26, 32, 32, 32, 1), (2, 24, 40, 16, 64, 16, 1)])
 @pytest.mark.parametrize("form", ["strip", "tile"])
 def test_fused_inverted_residual(n, h, w, cin, hidden, cout, stride, form):
     from pytorch_yolo_amd import kernels as K
