@@ -132,9 +132,7 @@ __global__ __launch_bounds__(256, 2) void resunit64_t20_kernel(const RU20Args ra
   for (int it = 0; it < 8; ++it)
 #pragma unroll
     for (int i = 0; i < 2; ++i) acc1[it][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // (YOLO_RESUNIT_DEBUG bit 2048, timing only, results wrong: the halo is not waited for - the upper bound of what a form that
-  // fetches the next tile's halo under the current tile's work can gain)
-  if (!(a.debug & 2048)) wait_vmcnt<0>();                  // my own DMA pieces (and W1) have landed: nobody else's rows are read here
+  wait_vmcnt<0>();                                         // my own DMA pieces (and W1) have landed: nobody else's rows are read here
   RU_STAMP(1);
   static_for<2>([&](auto kcc) {
     constexpr int kc = decltype(kcc)::value;
@@ -441,9 +439,7 @@ __global__ __launch_bounds__(256, 2) void resunit_t20w_kernel(const RU20Args ra)
     // DMAs of this wave younger than chunk c's: chunks c + 1 .. min(c - 2 + NB, NXC - 1) (step k >= 1 issues chunk k - 1 + NB)
     constexpr int last = c == 0 ? NB - 1 : (c - 2 + NB < NXC - 1 ? c - 2 + NB : NXC - 1);
     constexpr int younger = (last > c ? last - c : 0) * PPW;
-    // (YOLO_RESUNIT_DEBUG bit 2048, timing only, results wrong: chunk 0 is not waited for - what a tile would cost if its first x chunk
-    // had been requested during the previous tile's epilogue: the upper bound of what a persistent form can gain)
-    if (c != 0 || !(a.debug & 2048)) wait_vmcnt<younger>();
+    wait_vmcnt<younger>();
     __builtin_amdgcn_s_barrier();
     if constexpr (c == 1) RU_STAMP(1);
     if constexpr (c >= 1 && c - 1 + NB < NXC) {

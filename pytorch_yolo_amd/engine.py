@@ -779,6 +779,16 @@ class Plan:
                 d = op.conv
                 d.n, d.h, d.w, d.cin = x.n, x.h, x.w, x.c
                 ops.append(op); op_nodes.append(nd)
+        # Diagnostic only (timing; results wrong): YOLO_SHRINK_OPS="i,j,..." makes launches i, j, ... of the list process ONE image instead
+        # of the batch - same list, same streams, the launch itself nearly free -, so that `bench.py` can measure what a launch family
+        # costs INSIDE the pipelined step (tools/marginal_cost.py), as opposed to alone on an idle chip.
+        shrink = os.environ.get("YOLO_SHRINK_OPS", "")
+        if shrink and not self.f32:
+            for i in (int(v) for v in shrink.split(",") if v.strip()):
+                op = ops[i]
+                if op.kind in (OP_STEM, OP_RESUNIT, OP_CONV) and op.splits < 2 and op.conv.n == self.rec.input.n and op.conv.n > 1 and not (
+                        op.kind == OP_CONV and any(hd["op"] == i for hd in self.heads)):
+                    ops[i] = self._sub_op(op, 0, op.conv.n)[0]
         ops, op_nodes, shift = self._depth_first(ops, op_nodes)
         if shift:
             splitk_ops = [(i + shift(i), wb, nc) for i, wb, nc in splitk_ops]
