@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 opening call on one box: GPU suite at HEAD, the headline bench line, the LDS / MFMA counter passes VERDICT r4 item 7 asks for
-# (program directly after --), and the sharded code path rehearsed with one rank (item 5).   bash tools/r5_first.sh -> gpurun_out/r5a_*
+# (program directly after --), and the sharded code path rehearsed with one rank (item 5).   bash tools/runs/r05/<this file> -> gpurun_out/r5a_*
 cd $GRAFT_REPO_ROOT
 O=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
