@@ -135,35 +135,56 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void mb
   const int xrow = EXPAND ? kXStride : estride;          // without an expand conv the tile IS E (hidden == cin)
   char* const xdst = EXPAND ? lx : le;
   uint4 pre[NPRE];
-  auto fetch = [&](int tile) {
-    const int tx = tile % a.tiles_x, r = tile / a.tiles_x, ty = r % a.tiles_y, b = r / a.tiles_y;
-    const int iy0 = ty * TH * S - 1, ix0 = tx * TW * S - 1;
+  // This thread's pieces, decomposed ONCE (round 5, late: the tile loop divided by the runtime chunk count twice per piece in fetch
+  // AND stash, and by the runtime tile counts three times per tile - ~350 of the ~600 instructions a tile costs a wave with all three
+  // phases' arithmetic off): LDS byte offset (0xffff: no such piece) | halo row << 16 | halo column << 24, and the element offset
+  // from the halo's origin pixel.
+  int pc_pos[NPRE], pc_goff[NPRE];
+#pragma unroll
+  for (int k = 0; k < NPRE; ++k) {
+    const int pc = tid + k * nt;
+    const int pix = pc / chunks, ch = pc - pix * chunks;
+    const int py = pix / IW, px = pix - py * IW;
+    pc_pos[k] = (pc < pieces ? pix * xrow + ch * 16 : 0xffff) | py << 16 | px << 24;      // (the x tile is < 64 KB, the halo < 256 wide)
+    pc_goff[k] = (py * a.w + px) * a.in_ct + ch * 8;
+  }
+  // tile cursors: (tx, ty, b) of a tile index advanced by gridDim.x without divisions
+  struct Cursor { int tile, tx, ty, b; };
+  const int G = (int)gridDim.x;
+  const int c_dtx = G % a.tiles_x, c_dr = G / a.tiles_x, c_dty = c_dr % a.tiles_y, c_db = c_dr / a.tiles_y;
+  auto cursor_at = [&](int tile) {
+    const int tx = tile % a.tiles_x, r = tile / a.tiles_x;
+    return Cursor{tile, tx, r % a.tiles_y, r / a.tiles_y};
+  };
+  auto advance = [&](Cursor& c) {
+    c.tile += G;
+    c.tx += c_dtx;
+    const int w0 = c.tx >= a.tiles_x;
+    c.tx -= w0 ? a.tiles_x : 0;
+    c.ty += c_dty + w0;
+    const int w1 = c.ty >= a.tiles_y;
+    c.ty -= w1 ? a.tiles_y : 0;
+    c.b += c_db + w1;
+  };
+  auto fetch = [&](const Cursor& c) {
+    const int iy0 = c.ty * TH * S - 1, ix0 = c.tx * TW * S - 1;
+    const bf16_t* const base = a.x + ((long)(c.b * a.h + iy0) * a.w + ix0) * a.in_ct + a.in_co;      // (formed, not read, for iy0 / ix0 = -1)
 #pragma unroll
     for (int k = 0; k < NPRE; ++k) {
-      const int pc = tid + k * nt;
+      const int iy = iy0 + ((pc_pos[k] >> 16) & 0xff), ix = ix0 + ((unsigned)pc_pos[k] >> 24);
       pre[k] = make_uint4(0, 0, 0, 0);
-      if (pc < pieces) {
-        const int pix = pc / chunks, ch = pc - pix * chunks;
-        const int iy = iy0 + pix / IW, ix = ix0 + pix % IW;
-        if ((unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w)
-          pre[k] = *reinterpret_cast<const uint4*>(a.x + ((long)(b * a.h + iy) * a.w + ix) * a.in_ct + a.in_co + ch * 8);
-      }
+      if ((pc_pos[k] & 0xffff) != 0xffff && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w) pre[k] = *reinterpret_cast<const uint4*>(base + pc_goff[k]);
     }
   };
   auto stash = [&]() {
 #pragma unroll
-    for (int k = 0; k < NPRE; ++k) {
-      const int pc = tid + k * nt;
-      if (pc < pieces) {
-        const int pix = pc / chunks, ch = pc - pix * chunks;
-        *reinterpret_cast<uint4*>(xdst + pix * xrow + ch * 16) = pre[k];
-      }
-    }
+    for (int k = 0; k < NPRE; ++k)
+      if ((pc_pos[k] & 0xffff) != 0xffff) *reinterpret_cast<uint4*>(xdst + (pc_pos[k] & 0xffff)) = pre[k];
   };
 
   const int c16 = lane & 15, q = lane >> 4;
-  int tile = blockIdx.x;
-  if (tile < a.n_tiles) fetch(tile);
+  Cursor cur = cursor_at((int)blockIdx.x), nxt = cur;     // the tile being computed; the tile whose halo is being fetched
+  if (cur.tile < a.n_tiles) fetch(nxt);
 #if defined(__HIP_DEVICE_COMPILE__)
   // The depthwise weights are in registers from here on, and hipcc is told so: it cannot count vector-memory operations across the
   // tile loop, and without this a "s_waitcnt vmcnt(0)" stood in front of the first FMA of the depthwise phase of EVERY tile (the
@@ -181,23 +202,27 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void mb
   // the loads themselves, one tile old.  The residual (x at the tile's centre pixels) is read into registers before the x tile is
   // overwritten.
   constexpr int kMaxPT = (16 + nw - 1) / nw;             // projection tiles per wave: P / 16 x cop / 16 <= 16 (launch_nt checks)
-  if (tile < a.n_tiles) {
+  // projection tile t of a wave -> (pixel-row tile, cout tile): cop / 16 is 1, 2 or 4 on every shipped shape (3: cout 33-48)
+  const int nct_p = a.cop / 16, nct_sh = nct_p == 4 ? 2 : nct_p == 2 ? 1 : 0;
+  auto proj_rt = [&](int t) { return nct_p == 3 ? t / 3 : t >> nct_sh; };
+  if (cur.tile < a.n_tiles) {
     stash();
-    if (tile + (int)gridDim.x < a.n_tiles && !(a.debug & 16)) fetch(tile + gridDim.x);
+    advance(nxt);
+    if (nxt.tile < a.n_tiles && !(a.debug & 16)) fetch(nxt);
     lds_barrier();
   }
-  for (; tile < a.n_tiles; tile += gridDim.x) {
-    const int tx = tile % a.tiles_x, r = tile / a.tiles_x, ty = r % a.tiles_y, b = r / a.tiles_y;
-    const int oy0 = ty * TH, ox0 = tx * TW;
+  for (; cur.tile < a.n_tiles; advance(cur)) {
+    const int b = cur.b;
+    const int oy0 = cur.ty * TH, ox0 = cur.tx * TW;
     const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
     // the residual values of this wave's projection tiles
     bf16x4 xres[kMaxPT];
     if (S == 1 && a.has_res) {                             // (a stride-2 block has no residual)
-      const int nct_p = a.cop / 16, ntl_p = (P / 16) * nct_p;
+      const int ntl_p = (P / 16) * nct_p;
 #pragma unroll
       for (int i = 0; i < kMaxPT; ++i) {
         const int t = wave + i * nw;
-        const int rt = t / nct_p, ct = t - rt * nct_p;
+        const int rt = proj_rt(t), ct = t - rt * nct_p;
         const int p = rt * 16 + c16, c0 = ct * 16 + q * 4;
         xres[i] = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
         if (t < ntl_p) xres[i] = *reinterpret_cast<const bf16x4*>(xdst + ((p / TW + 1) * IW + p % TW + 1) * xrow + c0 * 2);
@@ -278,16 +303,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void mb
     }
     if (a.debug & 256) __syncthreads(); else lds_barrier();
     // ---- the NEXT tile's x halo (fetched during this tile's first phases) -> LDS; the loads of the tile after it go out
-    if (tile + (int)gridDim.x < a.n_tiles) {
+    if (cur.tile + G < a.n_tiles) {
       stash();
-      if (tile + 2 * (int)gridDim.x < a.n_tiles && !(a.debug & 16)) fetch(tile + 2 * gridDim.x);
+      advance(nxt);
+      if (nxt.tile < a.n_tiles && !(a.debug & 16)) fetch(nxt);
     }
     // ---- D: y = D Wp^T + bp (+ x)
     if (!(a.debug & 8)) {
-      const int nct = a.cop / 16, ntl = (P / 16) * nct, ksteps = ce / 32;
+      const int nct = nct_p, ntl = (P / 16) * nct, ksteps = ce / 32;
       int ti = 0;
       for (int t = wave; t < ntl; t += nw, ++ti) {
-        const int rt = t / nct, ct = t - rt * nct;
+        const int rt = proj_rt(t), ct = t - rt * nct;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < ksteps; ++k) {
           const bf16x8 wf = *reinterpret_cast<const bf16x8*>(lwp + (ct * 16 + c16) * dstride + k * 64 + q * 16);
