@@ -269,7 +269,57 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void mb
     }
     if (EXPAND) { if (a.debug & 256) __syncthreads(); else lds_barrier(); }
     // ---- C: D = relu6(dw3x3(E) + bd)
-    if (dw_on && !(a.debug & 4)) {
+    if constexpr (S == 1 && NT >= 512) {
+      if (dw_on && !(a.debug & 4)) {
+      // Stride 1 (round 5, late): a task is a run of FOUR adjacent output pixels of a row x 4 channels - its 3 x 6 window of E is read
+      // once (18 eight-byte reads, the same as the two-pixel iteration below) and feeds 16 outputs instead of 8: half the LDS bytes and
+      // 13 instead of 22 instructions per output.  The phase is bound by LDS reads (the float32-E experiment: half the instructions,
+      // twice the bytes, same time), and the tile has fewer such tasks (TH x TW / 4 x ce / 4 = 576 at 144 hidden channels) than the
+      // workgroup has threads: one pass.  Every output sums bias, then its nine taps in (dy, dx) order as before: the same numbers.
+      constexpr int RUN = 4, RPR = TW / RUN, NRUN = TH * RPR;
+      static_assert(TW % RUN == 0, "runs");
+      for (int run = grp; run < NRUN; run += groups) {
+        const int oy = run / RPR, ox0 = (run - oy * RPR) * RUN;
+        const char* const e0 = le + (oy * IW + ox0) * estride + qd * 8;
+        f32x2 s[RUN][2];
+#pragma unroll
+        for (int u = 0; u < RUN; ++u) {
+          s[u][0] = f32x2{bdr[0], bdr[1]};
+          s[u][1] = f32x2{bdr[2], bdr[3]};
+        }
+        // one window row in registers at a time (the whole 3 x 6 window at once - 36 registers beside the 40 of the weights and the 16
+        // accumulators - spills under the 128-register cap; so does the 256-thread instance with its two sets of x pieces: it keeps
+        // the two-pixel form below)
+        u32x2 v[2][RUN + 2];
+#pragma unroll
+        for (int c = 0; c < RUN + 2; ++c) v[0][c] = *reinterpret_cast<const u32x2*>(e0 + c * estride);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          if (dy < 2) {                                    // the next window row is on its way while this one is multiplied
+#pragma unroll
+            for (int c = 0; c < RUN + 2; ++c) v[(dy + 1) & 1][c] = *reinterpret_cast<const u32x2*>(e0 + ((dy + 1) * IW + c) * estride);
+          }
+          f32x2 lo[RUN + 2], hi[RUN + 2];
+#pragma unroll
+          for (int c = 0; c < RUN + 2; ++c) lo[c] = bf16pair_to_f32(v[dy & 1][c][0]), hi[c] = bf16pair_to_f32(v[dy & 1][c][1]);
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int u = 0; u < RUN; ++u) {
+              s[u][0] = __builtin_elementwise_fma(lo[u + dx], wdr2[dy * 3 + dx][0], s[u][0]);
+              s[u][1] = __builtin_elementwise_fma(hi[u + dx], wdr2[dy * 3 + dx][1], s[u][1]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RUN; ++u) {
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (bf16_t)relu6(s[u][e >> 1][e & 1]);
+          *reinterpret_cast<bf16x4*>(ld + (oy * TW + ox0 + u) * dstride + qd * 8) = o;
+        }
+      }
+      }
+    } else if (dw_on && !(a.debug & 4)) {
       for (int p = grp; p < P; p += 2 * groups) {       // two pixels per iteration
         const bool two = p + groups < P;
         const int pp[2] = {p, two ? p + groups : p};
