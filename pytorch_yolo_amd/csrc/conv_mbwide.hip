@@ -204,6 +204,46 @@ __global__ __launch_bounds__(NT) void mbwide_kernel(const MbwArgs a) {
           wr[t][1] = f32x2{v[2], v[3]};
         }
         const f32x4 bv = *reinterpret_cast<const f32x4*>(wdc + 768 + qd * 4);
+        if constexpr (S == 1) {
+          // Stride 1 (round 5, late): a task is a run of FOUR adjacent output pixels of a row - its 3 x 6 window of E is read once
+          // (18 eight-byte reads for 16 outputs instead of 9 per 4): the phase is bound by LDS reads.  The last run of a row starts at
+          // TW - 4 and recomputes up to three pixels of its neighbour (identical values, stored twice) instead of masking.  Every
+          // output still sums its bias and nine taps in (dy, dx) order.
+          constexpr int RUN = 4, RPR = (TW + RUN - 1) / RUN, NRUN = TH * RPR;
+          for (int run = tid >> 4; run < NRUN; run += NT / 16) {
+            const int oy = run / RPR, r_ = run - oy * RPR;
+            const int ox0 = r_ * RUN < TW - RUN ? r_ * RUN : TW - RUN;
+            const char* e0 = le + (oy * IW + ox0) * kES + qd * 8;
+            f32x2 s0[RUN], s1[RUN];
+#pragma unroll
+            for (int u = 0; u < RUN; ++u) s0[u] = f32x2{bv[0], bv[1]}, s1[u] = f32x2{bv[2], bv[3]};
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+              f32x2 lo[RUN + 2], hi[RUN + 2];
+#pragma unroll
+              for (int c = 0; c < RUN + 2; ++c) {
+                const u32x2 v = *reinterpret_cast<const u32x2*>(e0 + (dy * IW + c) * kES);
+                lo[c] = bf16pair_to_f32(v[0]), hi[c] = bf16pair_to_f32(v[1]);
+              }
+#pragma unroll
+              for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int u = 0; u < RUN; ++u) {
+                  s0[u] = __builtin_elementwise_fma(lo[u + dx], wr[dy * 3 + dx][0], s0[u]);
+                  s1[u] = __builtin_elementwise_fma(hi[u + dx], wr[dy * 3 + dx][1], s1[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RUN; ++u) {
+              bf16x4 o;
+              o[0] = (bf16_t)relu6(s0[u][0]);
+              o[1] = (bf16_t)relu6(s0[u][1]);
+              o[2] = (bf16_t)relu6(s1[u][0]);
+              o[3] = (bf16_t)relu6(s1[u][1]);
+              *reinterpret_cast<bf16x4*>(ld + (oy * TW + ox0 + u) * kES + qd * 8) = o;
+            }
+          }
+        } else {
         for (int p = tid >> 4; p < P; p += NT / 16) {
           const int oy = p / TW, ox = p - oy * TW;
           const char* e0 = le + ((oy * S) * IW + ox * S) * kES + qd * 8;
@@ -222,6 +262,7 @@ __global__ __launch_bounds__(NT) void mbwide_kernel(const MbwArgs a) {
           o[2] = (bf16_t)relu6(s1[0]);
           o[3] = (bf16_t)relu6(s1[1]);
           *reinterpret_cast<bf16x4*>(ld + p * kES + qd * 8) = o;
+        }
         }
       }
       // Wp of this chunk has landed: it is older than the set-E DMAs this wave issued after phase B
