@@ -170,7 +170,10 @@ __global__ __launch_bounds__(64 * (WAVES_M * WAVES_N + NP)) void conv_igemm_bf16
     char* const xb = wb + BNL * ROWB;
     if (FAST) {
       const uint32_t tap_off = (uint32_t)(((st_dh * d.w + st_dw) * d.in_c_total + kc) * 2);
-      const uint32_t bit = 1u << tap;
+      // (1x1 convs take this path with any cin % 8 == 0 - round 5: a chunk beyond the last channel reads zeros; with one tap a K
+      // step cannot straddle taps whatever cin is.  The generic path cost EfficientNet's 16 / 24 / 40-channel expand convs a
+      // division per lane and stage.)
+      const uint32_t bit = (kc + chunk * 8 < d.cin) ? 1u << tap : 0u;
 #pragma unroll
       for (int it = 0; it < PIT; ++it) {
         if (it < lo || it >= hi) continue;
@@ -705,7 +708,8 @@ static int conv2d_launch_ex(const void* x, const void* w, const float* bias, con
                            : launch_cfg<64, 256, 1, 4, 32, 2, false, false, false, true>(a, s);
   }
   const int variant = conv_variant_override >= 0 ? conv_variant_override : 0;
-  const bool fast64 = d.cin % 64 == 0, fast32 = d.cin % 32 == 0;
+  const bool one_tap = d.ksize == 1 && d.cin % 8 == 0 && !(conv_debug_flags & 268435456);      // (bit 268435456: the generic path for them, A/B)
+  const bool fast64 = d.cin % 64 == 0, fast32 = d.cin % 32 == 0 || one_tap;
   const bool epi = d.out_dtype == YOLO_DT_BF16 && d.cout % 32 == 0 && d.out_c_offset % 8 == 0 && d.out_c_total % 8 == 0 &&
                    (!res || (d.res_c_offset % 8 == 0 && d.res_c_total % 8 == 0)) &&
                    (!y_aux || (d.aux_c_offset % 8 == 0 && d.aux_c_total % 8 == 0)) && !(conv_debug_flags & 16);
