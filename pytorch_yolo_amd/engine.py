@@ -784,11 +784,13 @@ class Plan:
         # costs INSIDE the pipelined step (tools/marginal_cost.py), as opposed to alone on an idle chip.
         shrink = os.environ.get("YOLO_SHRINK_OPS", "")
         if shrink and not self.f32:
+            heads = {hd["op"] for hd in self.heads if hd["op"] is not None}
             for i in (int(v) for v in shrink.split(",") if v.strip()):
                 op = ops[i]
-                if op.kind in (OP_STEM, OP_RESUNIT, OP_CONV) and op.splits < 2 and op.conv.n == self.rec.input.n and op.conv.n > 1 and not (
-                        op.kind == OP_CONV and any(hd["op"] == i for hd in self.heads)):
-                    ops[i] = self._sub_op(op, 0, op.conv.n)[0]
+                if i not in heads and op.splits < 2 and op.conv.n == self.rec.input.n and op.conv.n > 1:
+                    sub = YoloOp.from_buffer_copy(op)      # image 0 only: every batch-major pointer already points at it
+                    sub.conv.n = 1
+                    ops[i] = sub
         ops, op_nodes, shift = self._depth_first(ops, op_nodes)
         if shift:
             splitk_ops = [(i + shift(i), wb, nc) for i, wb, nc in splitk_ops]

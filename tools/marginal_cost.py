@@ -20,9 +20,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def rows(path):
     out = []
     for ln in open(path):
-        m = re.match(r"\s*(\d+)\s+(\w+)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d)\s+(\d)\s+([\d.]+)\s+([\d.]+)?", ln)
+        m = re.match(r"\s*(\d+)\s+(\w+)\s+(\d+)\s+(\d+)\s+(\d*)\s+(\d)\s+(\d)\s+([\d.]+)\s+([\d.]+)?", ln)
         if m:
-            i, kind, M, N, K, k, s, ms = int(m[1]), m[2], int(m[3]), int(m[4]), int(m[5]), int(m[6]), int(m[7]), float(m[8])
+            i, kind, M, N, K, k, s, ms = int(m[1]), m[2], int(m[3]), int(m[4]), int(m[5] or 0), int(m[6]), int(m[7]), float(m[8])
             out.append(dict(i=i, kind=kind, M=M, N=N, K=K, k=k, s=s, ms=ms, head="head" in ln))
     return out
 
@@ -46,9 +46,13 @@ def main():
     def add(name, r):
         fam.setdefault(name, []).append(r)
     for r in table:
-        if r["head"] or r["kind"] not in ("conv", "stem", "resunit"):
+        if r["head"]:
             continue
-        if r["kind"] in ("stem", "resunit") or r["M"] >= mmax // 4 and r["i"] < 6:
+        if "--each" in sys.argv:
+            add(f"{r['i']:2d} {r['kind']} M {r['M']} N {r['N']} K {r['K']} k{r['k']} s{r['s']}", r)
+        elif r["kind"] not in ("conv", "stem", "resunit"):
+            continue
+        elif r["kind"] in ("stem", "resunit") or r["M"] >= mmax // 4 and r["i"] < 6:
             add("first stages (stem, fused units, 320->160)", r)
         elif r["s"] == 2:
             add("3x3 / stride 2 (the others)", r)
