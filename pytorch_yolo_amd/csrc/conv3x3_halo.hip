@@ -231,7 +231,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv3x3_halo_kernel(co
 // NHWC8 in LDS (16 B per pixel); K = 10 taps x 8 channels (tap 9 and channels >= c carry zero weights), i.e.
 // five 32x32x16 MFMAs per 32 pixels with the weight fragments held in registers.  The layer is HBM-bound
 // (write 64 B per pixel); the implicit-GEMM kernel spent its time issuing nine 16-byte gathers per pixel.
-constexpr int kConv1TilesPerBlock = 5;
+// Tiles per workgroup, swept on YOLOv3-tiny's first layer at 32 images of 416x416 (round 5, profiles/r05_conv1_tiles_per_workgroup.txt):
+// 2: 0.088 ms, 3: 0.071, 4: 0.071, 5 (rounds 3-4): 0.077, 6: 0.087, 7: 0.094 - more, shorter workgroups hide one another's start-up
+// better than longer runs amortise it; end to end 3: 90.5 k, 4: 89.1 k, 5: 88.2 k images/s.
+#ifndef YOLO_CONV1_TPB
+#define YOLO_CONV1_TPB 3
+#endif
+constexpr int kConv1TilesPerBlock = YOLO_CONV1_TPB;
 
 // COUT = 32 or 16 output channels (rows COUT..31 of the MFMA tile carry zero weights); POOL fuses the MaxPool2d(2, 2)
 // that follows the first ConvBlock of YOLOv3-tiny (reference models/yolo_base.py:69-80, yolov3_tiny.py:26): the 16 x 16
